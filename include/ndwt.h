@@ -1,0 +1,113 @@
+/*
+ * ndwt.h -- C ABI of the MI355X-native non-decimated wavelet transform engine (libndwt_hip.so).
+ *
+ * This is the drop-in boundary for the reference's native hot path:
+ *   reference mex/nddwt.h:13-32   nd_dwt_dec / nd_dwt_rec / nd_dwt_{dec,rec}_1level / pointByPoint /
+ *                                 init_fftw_plan      (the FFT-domain core, complex fp64 only)
+ *   reference mex/nd_dwt_mex.c:8  mexFunction         (the MATLAB gateway the classes call:
+ *                                 nd_dwt_1D.m:158,220  nd_dwt_2D.m:160,222  nd_dwt_3D.m:161,225
+ *                                 nd_dwt_4D.m:158,219)
+ *
+ * The reference hands FFT-domain data (x_f, f_dec) across that boundary; this engine takes the
+ * SIGNAL-domain array and a plan that carries the per-axis Daubechies taps, and computes the same
+ * coefficients with direct periodic filter banks in hand-written HIP kernels (gfx950).  Plain C types
+ * only: pointers, sizes, int status codes.  No torch, no C++ types.
+ *
+ * Layout (identical to the reference, nd_dwt_mex.c:72-83): column-major, dims[0] fastest; coefficient
+ * arrays are band-planar with the band axis last, bands = 2^d + (2^d-1)(level-1); band 0 is the coarsest
+ * approximation, the last 2^d-1 bands are the level-1 details; inside a level band b uses the high-pass
+ * on axis a iff bit a of b is set (Functions/nd_dwt_3D.m:45-52,334-341).
+ *
+ * Threading: a plan may be used by one host thread at a time; different plans are independent.
+ * Every compute entry point is asynchronous on the given HIP stream unless it takes host pointers.
+ */
+#ifndef NDWT_H
+#define NDWT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NDWT_MAX_DIMS 4
+#define NDWT_MAX_TAPS 20 /* db10 */
+
+typedef struct ndwt_plan ndwt_plan; /* opaque */
+
+/* status codes (the reference core returns void and cannot fail cleanly; nd_dwt_mex.c raises
+ * "MATLAB:FFT2mx:invalidNumInputs" for every error -- the mex shim maps these codes onto that) */
+enum {
+    NDWT_OK = 0,
+    NDWT_ERR_INVALID_ARG = 1,  /* bad ndim / dims / level / null pointer */
+    NDWT_ERR_UNKNOWN_WAVELET = 2, /* wave_filters.m:159 "Unknown Wavelet Name" */
+    NDWT_ERR_FILTER_TOO_LONG = 3, /* nd_dwt_3D.m:277-286 "... Dimension of Data is shorter than the wavelet filter being used" */
+    NDWT_ERR_NO_DEVICE = 4,    /* no HIP device / HIP runtime failure at plan creation */
+    NDWT_ERR_HIP = 5,          /* a HIP call failed; see ndwt_last_error() */
+    NDWT_ERR_ALLOC = 6,
+    NDWT_ERR_UNSUPPORTED = 7
+};
+
+enum { NDWT_F32 = 0, NDWT_F64 = 1 };                 /* 'precision' = single / double (nd_dwt_3D.m:130-132) */
+enum { NDWT_REAL = 0, NDWT_COMPLEX_INTERLEAVED = 1 }; /* split complex: call twice (re, im) -- the filters are real */
+enum { NDWT_DILATION_REFERENCE = 0, /* same un-dilated taps at every level: what the reference computes (nd_dwt_3D.m:178-186, nddwt.c:214-234) */
+       NDWT_DILATION_ATROUS = 1 };   /* tap stride 2^(level-1): textbook stationary wavelet transform */
+enum { NDWT_PATH_AUTO = 0,    /* fused kernels where they apply, per-axis kernels otherwise */
+       NDWT_PATH_GENERIC = 1  /* force the per-axis kernels (used by the parity tests to cross-check the fused ones) */ };
+
+/* ---- filters: Functions/wave_filters.m:1-174 ------------------------------------------------------
+ * wname = "db1" .. "db10" (case-insensitive).  Writes LO_D and HI_D (length *len = 2K) exactly as the
+ * reference returns them: LO_D[m] = h[L-1-m], HI_D[m] = (-1)^(m+1) h[m].  Buffers hold NDWT_MAX_TAPS. */
+int ndwt_wave_filters(const char* wname, double* lo_d, double* hi_d, int* len);
+
+/* ---- band bookkeeping -------------------------------------------------------------------------------
+ * nd_dwt_mex.c:83 and the level inference of rec() (nd_dwt_1D.m:213, 2D:215, 3D:217, 4D:213). */
+int64_t ndwt_num_bands(int ndim, int level);
+int ndwt_level_from_bands(int ndim, int64_t bands); /* returns level >= 1, or -1 if `bands` is not a valid count */
+
+/* ---- plan: replaces the class constructor's get_filters() (nd_dwt_3D.m:263-342) and the per-call
+ *      FFTW planning of nddwt.c:110-111 ----------------------------------------------------------------
+ * ndim 1..4; dims[0] fastest; wnames[a] per axis; dtype NDWT_F32/F64; complexity NDWT_REAL or
+ * NDWT_COMPLEX_INTERLEAVED; pres_l2_norm as in the classes; dilation NDWT_DILATION_*; max_level = the
+ * largest level dec/rec will be asked for (sizes the scratch); device = HIP device ordinal. */
+int ndwt_plan_create(ndwt_plan** plan, int ndim, const int64_t* dims, const char* const* wnames, int dtype,
+                     int complexity, int pres_l2_norm, int dilation, int max_level, int device);
+int ndwt_plan_destroy(ndwt_plan* plan);
+int ndwt_plan_set_path(ndwt_plan* plan, int path); /* NDWT_PATH_* */
+/* which kernels a level of this plan runs: writes a short static string such as "fused3d", "fused2d",
+ * "axis" into buf (for tests and logs) */
+int ndwt_plan_describe(const ndwt_plan* plan, char* buf, int buflen);
+
+/* ---- the transform: replaces nd_dwt_dec / nd_dwt_rec (nddwt.c:189-292) and the 1-level forms
+ *      (nddwt.c:98-186) -----------------------------------------------------------------------------------
+ * x: prod(dims) elements (x2 scalars if complex); y: prod(dims)*ndwt_num_bands(ndim, level) elements.
+ * Device pointers, caller-allocated, inputs are never modified (the reference's rec overwrites its
+ * input, nddwt.c:163).  stream is a hipStream_t passed as void* (NULL = the null stream). */
+int ndwt_dec(ndwt_plan* plan, const void* x_dev, void* y_dev, int level, void* stream);
+int ndwt_rec(ndwt_plan* plan, const void* y_dev, void* x_dev, int level, void* stream);
+
+/* Host-pointer forms for the mex shim (stage through device memory, synchronous). */
+int ndwt_dec_host(ndwt_plan* plan, const void* x_host, void* y_host, int level);
+int ndwt_rec_host(ndwt_plan* plan, const void* y_host, void* x_host, int level);
+
+/* ---- one level on a slab of the outermost axis (multi-GPU building block; no reference counterpart:
+ *      the reference is single-process) ------------------------------------------------
+ * The plan's dims describe the LOCAL slab (dims[ndim-1] = local planes).  `stride` is the tap stride of
+ * this level (1 in reference mode).  Analysis: `in` holds halo_before + local + halo_after planes of the
+ * approximation band, halo_before = (L/2-1)*stride, halo_after = (L/2)*stride for the outer axis' filter
+ * length L; the 2^d outputs are local-sized.  Synthesis: every one of the 2^d inputs holds
+ * halo_before = (L/2)*stride and halo_after = (L/2-1)*stride planes around the local slab.
+ * ndwt_slab_halo() reports those four numbers. */
+int ndwt_slab_halo(const ndwt_plan* plan, int stride, int64_t* ana_before, int64_t* ana_after,
+                   int64_t* syn_before, int64_t* syn_after);
+int ndwt_analysis_level_slab(ndwt_plan* plan, const void* in_with_halo, void* const* out_bands, int stride, void* stream);
+int ndwt_synthesis_level_slab(ndwt_plan* plan, const void* const* in_bands_with_halo, void* out, int stride, void* stream);
+
+/* ---- errors ------------------------------------------------------------------------------------------ */
+const char* ndwt_last_error(void); /* thread-local message of the last failing call */
+const char* ndwt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NDWT_H */

@@ -1,0 +1,7 @@
+// fused 3-D inv level, float
+#include "ndwt_fused_kernels.h"
+namespace ndwt {
+int launch_inv3_f32(const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, hipStream_t s) {
+    NDWT_FUSED_SWITCH(Inv3, float)
+}
+}  // namespace ndwt

@@ -1,0 +1,35 @@
+// ndwt_geom.h -- launch geometry of the fused kernels (shared by the library and the host emulator).
+#pragma once
+#include <cstdint>
+
+#include "ndwt_device.h"
+
+namespace ndwt {
+
+// fills the tiling fields of `a` (n1,n2,n3,nbatch must be set).  Workgroups march `zchunk` output
+// planes each; the chunk is sized so the grid has at least ~target_blocks workgroups (>> 256 CUs)
+// while the (L-1)-plane march prologue stays a small fraction of the chunk.
+template <typename T>
+inline void fused3_geometry(Fused3Args<T>& a, int TX, int TY, int Lp, int target_blocks = 2048, int force_zchunk = 0) {
+    a.ntx = (a.n1 + TX - 1) / TX;
+    a.nty = (a.n2 + TY - 1) / TY;
+    a.plane = (long long)a.n1 * a.n2;
+    long long per_chunk = (long long)a.ntx * a.nty * a.nbatch;
+    int want = (int)((target_blocks + per_chunk - 1) / per_chunk);
+    if (want < 1) want = 1;
+    int zc = (a.n3 + want - 1) / want;
+    int min_chunk = 4 * (Lp - 1);                 // prologue <= 25 % of the chunk
+    if (min_chunk < 8) min_chunk = 8;
+    if (zc < min_chunk) zc = min_chunk;
+    if (zc > a.n3) zc = a.n3;
+    if (force_zchunk > 0) zc = force_zchunk < a.n3 ? force_zchunk : a.n3;
+    a.zchunk = zc;
+    a.nzc = (a.n3 + zc - 1) / zc;
+}
+
+// the fused kernels keep intra-plane offsets in 32-bit ints
+inline bool fused3_fits(long long n1, long long n2, long long n3, long long nbatch) {
+    return n1 * n2 < (1LL << 31) && n3 < (1LL << 30) && nbatch < (1LL << 20) && n1 >= 1 && n2 >= 1 && n3 >= 1;
+}
+
+}  // namespace ndwt

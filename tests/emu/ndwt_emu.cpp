@@ -1,0 +1,98 @@
+// Host emulation of the fused HIP kernels -- TEST INFRASTRUCTURE, not a product path.
+// Compiles non-decimated_wavelets_amd/csrc/ndwt_device.h with NDWT_HOST_EMU (plain C++, clang) and
+// runs every workgroup's threads sequentially between barriers, under AddressSanitizer/UBSan, so
+// out-of-bounds global/LDS indexing is caught on the CPU before a kernel ever reaches a GPU.
+// (GPU AddressSanitizer is not available on the pool.)  The library never links this file.
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#define NDWT_HOST_EMU 1
+#include "ndwt_device.h"
+#include "ndwt_geom.h"
+
+namespace {
+
+template <class State, int NT> struct EmuExec {
+    std::vector<State> st;
+    EmuExec() : st(NT) {}
+    template <class F> void each(F&& f) {
+        for (int tid = 0; tid < NT; ++tid) f(tid, st[tid]);
+    }
+    void barrier() {}
+};
+
+template <class K, typename T>
+int run(ndwt::Fused3Args<T>& a, const double* lo, const double* hi) {
+    typename K::Taps tp;
+    for (int ax = 0; ax < 3; ++ax)
+        for (int j = 0; j < K::L; ++j) {
+            tp.lo[ax][j] = (T)lo[ax * ndwt::kMaxTaps + j];
+            tp.hi[ax][j] = (T)hi[ax * ndwt::kMaxTaps + j];
+        }
+    const int nblocks = a.ntx * a.nty * a.nzc * a.nbatch;
+    // LDS image on the heap with exact size so ASan sees overruns
+    for (int b = 0; b < nblocks; ++b) {
+        std::unique_ptr<typename K::Shared> sh(new typename K::Shared);
+        EmuExec<typename K::State, K::NT> ex;
+        K::block(ex, *sh, a, tp, b);
+    }
+    return 0;
+}
+
+template <typename T, template <typename, int, int, int, int, int, bool> class KIND, int TX, int TY, int NT, int RY>
+int dispatch(int Lp, int vec4, ndwt::Fused3Args<T>& a, const double* lo, const double* hi) {
+#define CASE(LL)                                                              \
+    case LL:                                                                  \
+        return vec4 ? run<KIND<T, LL, TX, TY, NT, RY, true>, T>(a, lo, hi)    \
+                    : run<KIND<T, LL, TX, TY, NT, RY, false>, T>(a, lo, hi);
+    switch (Lp) {
+        CASE(2) CASE(4) CASE(6) CASE(8) CASE(12)
+        default: return -1;
+    }
+#undef CASE
+}
+
+template <typename T>
+int emu3(int inverse, int Lp, int vec4, const T* in, T* out, int n1, int n2, int n3, int nbatch, int zchunk,
+         const double* lo, const double* hi, int z_wrap, int small_tile) {
+    ndwt::Fused3Args<T> a;
+    std::memset(&a, 0, sizeof(a));
+    a.n1 = n1; a.n2 = n2; a.n3 = n3; a.nbatch = nbatch;
+    const long long vol = (long long)n1 * n2 * n3;
+    const int halo = Lp - 1;
+    const long long vol_in = z_wrap ? vol : (long long)n1 * n2 * (n3 + halo);
+    a.z_wrap = z_wrap;
+    if (!inverse) {
+        a.in[0] = in;
+        for (int b = 0; b < 8; ++b) a.out[b] = out + b * vol * nbatch;
+        a.in_bstride = vol_in; a.out_bstride = vol;
+    } else {
+        for (int b = 0; b < 8; ++b) a.in[b] = in + b * vol_in * nbatch;
+        a.out[0] = out;
+        a.in_bstride = vol_in; a.out_bstride = vol;
+    }
+    if (small_tile) {   // a second tile shape exercises different item/lane mappings
+        ndwt::fused3_geometry(a, 16, 8, Lp, 2048, zchunk);
+        return inverse ? dispatch<T, ndwt::Inv3, 16, 8, 64, 2>(Lp, vec4, a, lo, hi)
+                       : dispatch<T, ndwt::Fwd3, 16, 8, 64, 2>(Lp, vec4, a, lo, hi);
+    }
+    ndwt::fused3_geometry(a, 64, 16, Lp, 2048, zchunk);
+    return inverse ? dispatch<T, ndwt::Inv3, 64, 16, 256, 4>(Lp, vec4, a, lo, hi)
+                   : dispatch<T, ndwt::Fwd3, 64, 16, 256, 4>(Lp, vec4, a, lo, hi);
+}
+
+}  // namespace
+
+extern "C" {
+// in/out: band-planar, batch inside band: [band][batch][n3(+halo)][n2][n1]; lo/hi: [3][20] padded kernel-form taps
+int ndwt_emu3_f32(int inverse, int Lp, int vec4, const float* in, float* out, int n1, int n2, int n3, int nbatch,
+                  int zchunk, const double* lo, const double* hi, int z_wrap, int small_tile) {
+    return emu3<float>(inverse, Lp, vec4, in, out, n1, n2, n3, nbatch, zchunk, lo, hi, z_wrap, small_tile);
+}
+int ndwt_emu3_f64(int inverse, int Lp, int vec4, const double* in, double* out, int n1, int n2, int n3, int nbatch,
+                  int zchunk, const double* lo, const double* hi, int z_wrap, int small_tile) {
+    return emu3<double>(inverse, Lp, vec4, in, out, n1, n2, n3, nbatch, zchunk, lo, hi, z_wrap, small_tile);
+}
+}

@@ -1,0 +1,91 @@
+"""Host emulation of the fused HIP kernels (same source, clang + ASan/UBSan) against the oracle.
+
+Catches indexing mistakes (global and LDS out-of-bounds, wrong halo/wrap arithmetic, band order) on
+the CPU; the -m gpu tests then check the real kernels.  Reference semantics: one level of
+Functions/nd_dwt_3D.m:345-374 (level_1_dec / level_1_rec).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import ndwt_oracle as orc
+from helpers import kernel_taps, to_kernel_order
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_SO = os.path.join(ROOT, "tests", "emu", "libndwt_emu.so")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    if not os.path.exists(EMU_SO):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "emu")])
+    # ASan must be loaded first when the host program (python) is not instrumented
+    if "libclang_rt.asan" not in os.environ.get("LD_PRELOAD", ""):
+        pytest.skip("run through tests/emu/run_emu_tests.sh (needs LD_PRELOAD of the ASan runtime)")
+    return ctypes.CDLL(EMU_SO)
+
+
+def _run(emu, x_mat_or_bands, wnames, l2, inverse, dtype, vec4, zchunk, small, z_wrap=1):
+    Ls = [len(orc.wave_filters(w)[0]) for w in wnames]
+    Lp = max(Ls)
+    lo = np.zeros((3, 20))
+    hi = np.zeros((3, 20))
+    for ax in range(3):
+        t = kernel_taps(wnames[ax], l2, Lp)
+        lo[ax, :Lp] = t["syn_lo" if inverse else "ana_lo"]
+        hi[ax, :Lp] = t["syn_hi" if inverse else "ana_hi"]
+    src = to_kernel_order(x_mat_or_bands).astype(dtype)
+    if inverse:
+        n3, n2, n1 = src.shape[1:]
+        out = np.full((n3, n2, n1), np.nan, dtype=dtype)
+    else:
+        n3, n2, n1 = src.shape
+        out = np.full((8, n3, n2, n1), np.nan, dtype=dtype)
+    fn = emu.ndwt_emu3_f32 if dtype == np.float32 else emu.ndwt_emu3_f64
+    fn.restype = ctypes.c_int
+    rc = fn(int(inverse), Lp, int(vec4), src.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p),
+            n1, n2, n3, 1, zchunk, lo.ctypes.data_as(ctypes.c_void_p), hi.ctypes.data_as(ctypes.c_void_p), z_wrap,
+            int(small))
+    assert rc == 0
+    return np.transpose(out)
+
+
+CASES = [
+    # sizes (n1,n2,n3),      wavelets,               vec4,  zchunk, small_tile
+    ((16, 9, 7), ("db1", "db3", "db2"), True, 0, True),
+    ((13, 10, 9), ("db2", "db2", "db2"), False, 4, True),
+    ((20, 17, 12), ("db4", "db4", "db4"), True, 5, True),
+    ((68, 18, 9), ("db4", "db4", "db4"), True, 0, False),
+    ((70, 19, 10), ("db2", "db1", "db4"), False, 6, False),
+]
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("sizes,wn,vec4,zchunk,small", CASES)
+@pytest.mark.parametrize("l2", [0, 1])
+def test_emulated_fused3_analysis(emu, sizes, wn, vec4, zchunk, small, l2):
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(sizes)
+    filt = [orc.wave_filters(w) for w in wn]
+    want = orc.spatial_level_dec(x, filt, l2)
+    for dtype, tol in ((np.float64, 1e-13), (np.float32, 2e-6)):
+        got = _run(emu, x, wn, l2, False, dtype, vec4, zchunk, small)
+        assert np.isfinite(got).all()
+        assert np.abs(got - want).max() <= tol * np.abs(want).max()
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("sizes,wn,vec4,zchunk,small", CASES)
+@pytest.mark.parametrize("l2", [0, 1])
+def test_emulated_fused3_synthesis(emu, sizes, wn, vec4, zchunk, small, l2):
+    rng = np.random.default_rng(2)
+    c = rng.standard_normal(tuple(sizes) + (8,))
+    filt = [orc.wave_filters(w) for w in wn]
+    want = orc.spatial_level_rec(c, filt, l2)
+    for dtype, tol in ((np.float64, 1e-13), (np.float32, 2e-6)):
+        got = _run(emu, c, wn, l2, True, dtype, vec4, zchunk, small)
+        assert np.isfinite(got).all()
+        assert np.abs(got - want).max() <= tol * max(np.abs(want).max(), 1.0)
