@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- fwd+inv NDWT throughput on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+Workload at N=1: BASELINE config 3 -- 3-D fp32 512x512x512, db4, 3 levels, reference-parity dilation
+(stride-1 taps at every level, what the reference computes), pres_l2_norm on, synthetic N(0,1) input resident
+in HBM.  A step = dec(x, 3) followed by rec(y).  N>1: the same 512^3 volume sharded on the outermost axis
+(strong scaling), periodic halo exchange per level through torch.distributed (RCCL).
+
+Algorithmic bytes: each level-direction launch moves (1 + 2^d) V sizeof(T) = 36 B/voxel;
+fwd+inv over 3 levels = 216 B/voxel.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s is the measured copy ceiling)
+
+
+def cpu_baseline(level, wname, sample_sizes, workers):
+    """The reference's algorithm (FFT-domain fast convolution, op sequence of mex/nddwt.c) restated with scipy.fft on
+    the host cores, complex128 like the mex path -- kind 'port'.  Timed on a bounded sample of the workload.
+    Arrays are band-planar with each band contiguous, the reference's column-major layout."""
+    import numpy as np
+    import scipy.fft as sfft
+    import ndwt_oracle as orc
+    d = len(sample_sizes)
+    nb = 1 << d
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(sample_sizes)
+    m = orc.NdDwtMat(wname, sample_sizes, 1, compute="mex")       # f_dec incl. the 1/N of the mex path; construction is
+    f_dec = np.ascontiguousarray(np.moveaxis(m.f_dec, -1, 0))     # untimed, like the class constructor
+    axes = tuple(range(1, d + 1))
+    nbt = orc.num_bands(d, level)
+    t0 = time.perf_counter()
+    with sfft.set_workers(workers):
+        # dec: nd_dwt_3D.m:157 + nddwt.c:189-239
+        approx = sfft.fftn(x)
+        out = np.empty([nbt] + list(sample_sizes), dtype=np.complex128)
+        for lev in range(level, 0, -1):
+            s0 = (nb - 1) * (lev - 1)
+            out[s0:s0 + nb] = sfft.ifftn(approx[None] * f_dec, axes=axes, norm="forward")   # pointByPoint + batched inverse
+            approx = sfft.fftn(out[s0])
+        y = out.real
+        # rec: nd_dwt_3D.m:220 + nddwt.c:242-292
+        c_f = sfft.fftn(y, axes=axes)
+        cur = None
+        for ind in range(1, level + 1):
+            s0 = (nb - 1) * (ind - 1)
+            if cur is not None:
+                c_f[s0] = sfft.fftn(cur)
+            cur = sfft.ifftn(c_f[s0:s0 + nb] * np.conj(f_dec), axes=axes, norm="forward").sum(axis=0)
+        r = cur.real
+    dt = time.perf_counter() - t0
+    err = float(np.abs(r - x).max())
+    assert err < 1e-9, err
+    return float(np.prod(sample_sizes)) / dt / 1e6, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, nargs=3, default=[512, 512, 512])
+    ap.add_argument("--wname", default="db4")
+    ap.add_argument("--level", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--generic", action="store_true", help="force the per-axis kernels (for comparison)")
+    ap.add_argument("--zchunk", type=int, default=0)
+    ap.add_argument("--target-blocks", type=int, default=0)
+    a = ap.parse_args()
+
+    import torch
+    import importlib
+    pkg = importlib.import_module("non-decimated_wavelets_amd")
+    api = importlib.import_module("non-decimated_wavelets_amd.api")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", device_id=dev)
+
+    n1, n2, n3 = a.size
+    V = n1 * n2 * n3
+    level = a.level
+    nb = api.num_bands(3, level)
+    torch.manual_seed(1234 + rank)
+
+    if world == 1:
+        plan = api.Plan([n1, n2, n3], [a.wname] * 3, torch.float32, False, True, "reference", max_level=max(level, 3), device=local_rank)
+        plan.set_path(a.generic)
+        plan.set_tuning(a.target_blocks, a.zchunk)
+        x = torch.randn(n3, n2, n1, device=dev, dtype=torch.float32)
+        y = torch.empty(nb, n3, n2, n1, device=dev, dtype=torch.float32)
+        r = torch.empty_like(x)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+
+        def step():
+            plan.dec(x.data_ptr(), y.data_ptr(), level, stream)
+            plan.rec(y.data_ptr(), r.data_ptr(), level, stream)
+        kinds = (2, 3) if a.generic else (0, 1)
+    else:
+        sh = importlib.import_module("non-decimated_wavelets_amd.sharded")
+        eng = sh.ShardedNdDwt([a.wname] * 3, [n1, n2, n3], pres_l2_norm=True, precision="single", group=dist.group.WORLD, device=dev)
+        x = torch.randn(eng.n_local, n2, n1, device=dev, dtype=torch.float32)
+        plan = eng.plan
+
+        def step():
+            yl = eng.dec(x, level)
+            eng.rec(yl)
+        kinds = (0, 1)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    plan.set_profiling(True)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    prof = {k: plan.get_profile(k) for k in kinds}
+    plan.set_profiling(False)
+
+    # round-trip check on the timed data (world == 1)
+    rt_err = None
+    if world == 1:
+        rt_err = float(torch.linalg.vector_norm((r - x).double()) / torch.linalg.vector_norm(x.double()))
+
+    ms_per_step = dt / a.steps * 1e3
+    value = V / (dt / a.steps) / 1e6
+    esize = 4
+    v_local = V // world
+    bytes_per_launch = (1 + 8) * v_local * esize                 # one level, one direction (36 B/voxel fp32)
+    # dominant kernel = the kind with the larger total time
+    dom = max(kinds, key=lambda k: prof[k][0])
+    dom_ms, dom_n = prof[dom]
+    avg_ms = dom_ms / max(dom_n, 1)
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    names = {0: "fused3_synthesis" if False else "fused3_analysis", 1: "fused3_synthesis", 2: "axis_analysis", 3: "axis_synthesis"}
+    roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_ms": round(avg_ms, 4), "launches": int(dom_n),
+                "other_kernel": {"kernel": names[[k for k in kinds if k != dom][0]],
+                                 "avg_launch_ms": round(prof[[k for k in kinds if k != dom][0]][0] / max(prof[[k for k in kinds if k != dom][0]][1], 1), 4)},
+                "whole_step_frac": round((2 * level * bytes_per_launch * world) / (dt / a.steps) / 1e9 / (HBM_PEAK_GBS * world), 4)}
+
+    out = {"metric": "Mvoxels/s fwd+inv NDWT (512^3 fp32, 3 lvl db4)", "value": round(value, 1), "unit": "Mvoxels/s",
+           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"3D fp32 {n1}x{n2}x{n3} {a.wname} {level} levels, dec+rec, pres_l2_norm, reference dilation (stride 1)",
+                      "sharding": "none" if world == 1 else f"outer-axis slabs x{world}, periodic halo via RCCL send/recv",
+                      "path": "per-axis" if a.generic else "fused3d"},
+           "roofline": roofline}
+    if rt_err is not None:
+        out["roundtrip_rel_l2"] = rt_err
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cores = os.cpu_count() or 1
+        workers = min(cores, 16)
+        sample = [256, 256, 128] if cores >= 32 else [192, 192, 128]
+        v, secs = cpu_baseline(level, a.wname, sample, workers)
+        out["cpu_baseline"] = {"value": round(v, 2), "unit": "Mvoxels/s", "cores": workers, "kind": "port",
+                               "sample": f"{sample[0]}x{sample[1]}x{sample[2]} fp64/complex128 {a.wname} {level} levels dec+rec, FFT-domain "
+                                         f"restatement of mex/nddwt.c with scipy.fft workers={workers}; {secs:.1f} s"}
+    if rank == 0:
+        print(json.dumps(out))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

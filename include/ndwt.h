@@ -77,6 +77,15 @@ int ndwt_plan_set_path(ndwt_plan* plan, int path); /* NDWT_PATH_* */
 /* which kernels a level of this plan runs: writes a short static string such as "fused3d", "fused2d",
  * "axis" into buf (for tests and logs) */
 int ndwt_plan_describe(const ndwt_plan* plan, char* buf, int buflen);
+/* tuning hook (tests, benchmarks): workgroup count the fused kernels aim for and/or a forced number of
+ * outer-axis planes per workgroup; 0 restores the default.  Results never depend on it. */
+int ndwt_plan_set_tuning(ndwt_plan* plan, int target_blocks, int force_zchunk);
+/* per-kernel timing with HIP events recorded on the launch stream around every kernel this plan launches
+ * (what bench.py's roofline line is computed from).  ndwt_plan_get_profile() synchronises the device, sums and
+ * clears the records of one kernel kind. */
+enum { NDWT_KERNEL_FUSED_ANALYSIS = 0, NDWT_KERNEL_FUSED_SYNTHESIS = 1, NDWT_KERNEL_AXIS_ANALYSIS = 2, NDWT_KERNEL_AXIS_SYNTHESIS = 3 };
+int ndwt_plan_set_profiling(ndwt_plan* plan, int enable);
+int ndwt_plan_get_profile(ndwt_plan* plan, int kind, double* total_ms, int64_t* launches);
 
 /* ---- the transform: replaces nd_dwt_dec / nd_dwt_rec (nddwt.c:189-292) and the 1-level forms
  *      (nddwt.c:98-186) -----------------------------------------------------------------------------------

@@ -1,0 +1,99 @@
+"""ctypes binding of libndwt_hip.so (the C ABI declared in include/ndwt.h).
+
+The library is built in-tree by `make -C csrc` (hipcc, gfx950).  There is no CPU fallback: if the
+shared object is missing, or no HIP device is usable, the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libndwt_hip.so")
+
+# status codes / enums of include/ndwt.h
+NDWT_OK = 0
+NDWT_F32, NDWT_F64 = 0, 1
+NDWT_REAL, NDWT_COMPLEX_INTERLEAVED = 0, 1
+NDWT_DILATION_REFERENCE, NDWT_DILATION_ATROUS = 0, 1
+NDWT_PATH_AUTO, NDWT_PATH_GENERIC = 0, 1
+
+EXPORTS = [
+    "ndwt_wave_filters", "ndwt_num_bands", "ndwt_level_from_bands", "ndwt_plan_create", "ndwt_plan_destroy",
+    "ndwt_plan_set_path", "ndwt_plan_describe", "ndwt_plan_set_tuning", "ndwt_plan_set_profiling", "ndwt_plan_get_profile", "ndwt_dec", "ndwt_rec", "ndwt_dec_host",
+    "ndwt_rec_host", "ndwt_slab_halo", "ndwt_analysis_level_slab", "ndwt_synthesis_level_slab", "ndwt_last_error",
+    "ndwt_version",
+]
+
+
+class NdwtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ndwt error {code}: {msg}")
+        self.code = code
+        self.message = msg
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP extension in-tree (hipcc --offload-arch=gfx950)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j", str(min(8, os.cpu_count() or 1))]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout)
+    if r.returncode != 0:
+        raise RuntimeError("building libndwt_hip.so failed")
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension must be built first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C non-decimated_wavelets_amd/csrc). "
+            "This engine has no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    c_void_pp = ctypes.POINTER(ctypes.c_void_p)
+    L.ndwt_wave_filters.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                    ctypes.POINTER(ctypes.c_int)]
+    L.ndwt_num_bands.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.ndwt_num_bands.restype = ctypes.c_int64
+    L.ndwt_level_from_bands.argtypes = [ctypes.c_int, ctypes.c_int64]
+    L.ndwt_plan_create.argtypes = [c_void_pp, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_char_p),
+                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.ndwt_plan_destroy.argtypes = [ctypes.c_void_p]
+    L.ndwt_plan_set_path.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.ndwt_plan_set_tuning.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    L.ndwt_plan_set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.ndwt_plan_get_profile.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
+    L.ndwt_plan_describe.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+    for f in (L.ndwt_dec, L.ndwt_rec):
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    for f in (L.ndwt_dec_host, L.ndwt_rec_host):
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    L.ndwt_slab_halo.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.POINTER(ctypes.c_int64)] * 4
+    L.ndwt_analysis_level_slab.argtypes = [ctypes.c_void_p, ctypes.c_void_p, c_void_pp, ctypes.c_int, ctypes.c_void_p]
+    L.ndwt_synthesis_level_slab.argtypes = [ctypes.c_void_p, c_void_pp, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    L.ndwt_last_error.restype = ctypes.c_char_p
+    L.ndwt_version.restype = ctypes.c_char_p
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc != NDWT_OK:
+        raise NdwtError(rc, lib().ndwt_last_error().decode())
+
+
+def wave_filters(wname: str):
+    """(LO_D, HI_D) as lists -- Functions/wave_filters.m through the C ABI."""
+    lo = (ctypes.c_double * 20)()
+    hi = (ctypes.c_double * 20)()
+    n = ctypes.c_int(0)
+    check(lib().ndwt_wave_filters(wname.encode(), lo, hi, ctypes.byref(n)))
+    return list(lo[: n.value]), list(hi[: n.value])

@@ -1,0 +1,341 @@
+"""Host-side mirror of the reference's class API for the NDWT hot path.
+
+Reference: Functions/nd_dwt_1D.m, nd_dwt_2D.m, nd_dwt_3D.m, nd_dwt_4D.m -- constructor
+`nd_dwt_3D(wname, sizes, 'pres_l2_norm', b, 'compute', c, 'precision', p)`, `dec(x, level)`, `rec(y)`
+and the public properties (nd_dwt_3D.m:67-75).  Everything is computed by the HIP library behind
+include/ndwt.h; PyTorch only provides device memory and the current stream.
+
+Shapes follow MATLAB: x is `sizes` = [n1, ..., nd]; coefficients are [n1, ..., nd, bands] with the
+band order of the reference (nd_dwt_3D.m:45-52).  Memory is column-major like MATLAB's: the tensors
+returned are permuted views of contiguous (bands, nd, ..., n1) buffers, and column-major inputs are
+consumed without a copy.
+
+`compute` values: 'hip' -- torch tensors on the GPU in and out (the analogue of the reference's
+'gpu'); 'hip_off' -- host arrays (numpy / CPU tensors) in and out, staged through the GPU (the
+analogue of 'gpu_off').  The reference's own names are accepted as aliases for the data placement
+they imply ('gpu' -> 'hip'; 'gpu_off', 'mat', 'mex' -> 'hip_off'); the arithmetic is always the HIP
+engine's.  There is no CPU compute path.
+"""
+from __future__ import annotations
+
+import ctypes
+import warnings
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+_ORD = ["First", "Second", "Third", "Fourth"]
+
+
+class Plan:
+    """Thin RAII wrapper over ndwt_plan (include/ndwt.h)."""
+
+    def __init__(self, dims, wnames, dtype, complex_interleaved=False, pres_l2_norm=False, dilation="reference",
+                 max_level=1, device=0):
+        self.dims = [int(d) for d in dims]
+        self.ndim = len(self.dims)
+        self.wnames = list(wnames)
+        self.dtype = dtype
+        self.max_level = int(max_level)
+        self.device = int(device)
+        self._h = ctypes.c_void_p(None)
+        dims_c = (ctypes.c_int64 * self.ndim)(*self.dims)
+        names_c = (ctypes.c_char_p * self.ndim)(*[w.encode() for w in self.wnames])
+        dt = L.NDWT_F32 if dtype in (torch.float32, np.float32, "single") else L.NDWT_F64
+        dil = {"reference": L.NDWT_DILATION_REFERENCE, "atrous": L.NDWT_DILATION_ATROUS}[dilation]
+        L.check(L.lib().ndwt_plan_create(ctypes.byref(self._h), self.ndim, dims_c, names_c, dt,
+                                         L.NDWT_COMPLEX_INTERLEAVED if complex_interleaved else L.NDWT_REAL,
+                                         int(bool(pres_l2_norm)), dil, self.max_level, self.device))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                L.lib().ndwt_plan_destroy(self._h)
+                self._h = ctypes.c_void_p(None)
+        except Exception:
+            pass
+
+    def set_path(self, generic: bool):
+        L.check(L.lib().ndwt_plan_set_path(self._h, L.NDWT_PATH_GENERIC if generic else L.NDWT_PATH_AUTO))
+
+    def set_tuning(self, target_blocks=0, force_zchunk=0):
+        L.check(L.lib().ndwt_plan_set_tuning(self._h, int(target_blocks), int(force_zchunk)))
+
+    def set_profiling(self, on: bool):
+        L.check(L.lib().ndwt_plan_set_profiling(self._h, int(bool(on))))
+
+    def get_profile(self, kind: int):
+        """(total_ms, launches) of kernel kind 0 fused analysis, 1 fused synthesis, 2 axis analysis, 3 axis synthesis"""
+        ms, n = ctypes.c_double(0), ctypes.c_int64(0)
+        L.check(L.lib().ndwt_plan_get_profile(self._h, int(kind), ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    def describe(self) -> str:
+        buf = ctypes.create_string_buffer(64)
+        L.check(L.lib().ndwt_plan_describe(self._h, buf, 64))
+        return buf.value.decode()
+
+    def dec(self, x_ptr, y_ptr, level, stream=0):
+        L.check(L.lib().ndwt_dec(self._h, x_ptr, y_ptr, int(level), ctypes.c_void_p(stream)))
+
+    def rec(self, y_ptr, x_ptr, level, stream=0):
+        L.check(L.lib().ndwt_rec(self._h, y_ptr, x_ptr, int(level), ctypes.c_void_p(stream)))
+
+    def slab_halo(self, stride=1):
+        v = [ctypes.c_int64(0) for _ in range(4)]
+        L.check(L.lib().ndwt_slab_halo(self._h, int(stride), *[ctypes.byref(t) for t in v]))
+        return tuple(t.value for t in v)   # (ana_before, ana_after, syn_before, syn_after)
+
+    def analysis_level_slab(self, in_ptr, out_ptrs, stride=1, stream=0):
+        arr = (ctypes.c_void_p * len(out_ptrs))(*out_ptrs)
+        L.check(L.lib().ndwt_analysis_level_slab(self._h, in_ptr, arr, int(stride), ctypes.c_void_p(stream)))
+
+    def synthesis_level_slab(self, in_ptrs, out_ptr, stride=1, stream=0):
+        arr = (ctypes.c_void_p * len(in_ptrs))(*in_ptrs)
+        L.check(L.lib().ndwt_synthesis_level_slab(self._h, arr, out_ptr, int(stride), ctypes.c_void_p(stream)))
+
+
+def num_bands(ndim, level):
+    return int(L.lib().ndwt_num_bands(int(ndim), int(level)))
+
+
+def _current_stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class _NdDwtBase:
+    """Common implementation of nd_dwt_{1,2,3,4}D (reference files cited per method)."""
+
+    NDIM = 0
+
+    def __init__(self, wname, sizes, *varargin, **kwargs):
+        d = self.NDIM
+        sizes = [int(s) for s in np.atleast_1d(sizes)]
+        self._check_sizes(sizes)
+        self.sizes = sizes
+        self.wname = self._check_wname(wname)
+        # defaults: nd_dwt_3D.m:101-103 (compute defaults to the HIP engine here)
+        self.pres_l2_norm = 0
+        self.precision = "double"
+        self.compute = "hip"
+        self.dilation = "reference"
+        self.device = None
+        # name/value pairs as in MATLAB (nd_dwt_3D.m:105-120); keyword arguments are accepted too
+        if len(varargin) % 2:
+            raise ValueError("Optional inputs must come in pairs")
+        opts = [(varargin[i], varargin[i + 1]) for i in range(0, len(varargin), 2)] + list(kwargs.items())
+        for ind, (key, val) in enumerate(opts):
+            k = str(key).lower()
+            if k == "pres_l2_norm":
+                self.pres_l2_norm = int(bool(val))
+            elif k == "compute":
+                self.compute = str(val)
+            elif k == "precision":
+                self.precision = str(val)
+            elif k == "dilation":
+                self.dilation = str(val).lower()
+            elif k == "device":
+                self.device = val
+            else:   # unknown keys only warn (nd_dwt_3D.m:118)
+                warnings.warn(f"Unknown optional input #{2 * ind + 1} ingoring!")
+        if self.compute.lower() == "mex" and self.precision.lower() == "single":   # nd_dwt_3D.m:122-124
+            raise ValueError("Single precsision is not currently supported for mex computation")
+        c = self.compute.lower()
+        if c in ("hip", "gpu"):
+            self._offload = False
+        elif c in ("hip_off", "gpu_off", "mat", "mex"):
+            self._offload = True
+        else:
+            raise ValueError(f"unknown compute '{self.compute}'")
+        if self.precision.lower() not in ("double", "single"):
+            raise ValueError("precision must be 'double' or 'single'")
+        if self.dilation not in ("reference", "atrous"):
+            raise ValueError("dilation must be 'reference' or 'atrous'")
+        # get_filters (nd_dwt_3D.m:263-342): per-axis taps instead of N-D FFT-domain kernels
+        self.f_dec = [L.wave_filters(w) for w in self.wname[:d]]
+        self.f_size = {f"s{a + 1}": len(self.f_dec[a][0]) for a in range(d)}
+        for a in range(d):
+            if self.f_size[f"s{a + 1}"] > sizes[a]:   # nd_dwt_3D.m:277-286
+                raise ValueError(f"{_ORD[a]} Dimension of Data is shorter than the wavelet filter being used")
+        self._plans = {}
+
+    # -- per-dimension validation (messages of the reference) --
+    def _check_sizes(self, sizes):
+        raise NotImplementedError
+
+    def _check_wname(self, wname):
+        raise NotImplementedError
+
+    def _level_from_bands(self, n):
+        raise NotImplementedError
+
+    # -- plumbing --
+    def _torch_dtype(self, is_complex):
+        single = self.precision.lower() == "single"
+        if is_complex:
+            return torch.complex64 if single else torch.complex128
+        return torch.float32 if single else torch.float64
+
+    def _dev(self, x=None):
+        if self.device is not None:
+            return torch.device(self.device)
+        if x is not None and isinstance(x, torch.Tensor) and x.is_cuda:
+            return x.device
+        return torch.device("cuda", torch.cuda.current_device())
+
+    def _plan(self, is_complex, level, dev):
+        key = (is_complex, dev.index or 0)
+        p = self._plans.get(key)
+        if p is None or p.max_level < level:
+            real_dt = torch.float32 if self.precision.lower() == "single" else torch.float64
+            p = Plan(self.sizes, self.wname[: self.NDIM], real_dt, is_complex, self.pres_l2_norm, self.dilation,
+                     max_level=max(level, 3), device=dev.index or 0)
+            self._plans[key] = p
+        return p
+
+    def _to_device_kernel_order(self, x, dev, ndim_expected):
+        """user array (MATLAB shape) -> contiguous tensor in kernel order (reversed dims) on `dev`."""
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(np.ascontiguousarray(np.transpose(x)))     # kernel order on the host
+            kernel_order = True
+        else:
+            kernel_order = False
+        if not isinstance(x, torch.Tensor):
+            raise TypeError("x must be a torch.Tensor or numpy.ndarray")
+        if not self._offload and not x.is_cuda:
+            raise ValueError("compute='hip' expects tensors on the GPU (use compute='hip_off' for host arrays)")
+        if not kernel_order:
+            x = x.permute(*reversed(range(x.dim())))
+        dt = self._torch_dtype(x.is_complex())
+        return x.to(device=dev, dtype=dt).contiguous()
+
+    def _from_device(self, t_kernel, like_numpy, dev_in):
+        out = t_kernel.permute(*reversed(range(t_kernel.dim())))            # MATLAB shape, column-major memory
+        if self._offload:
+            out = out.cpu()
+            if like_numpy:
+                return out.numpy()
+        return out
+
+    # -- nd_dwt_3D.m:142-199 --
+    def dec(self, x, level):
+        level = int(level)
+        if level < 1:
+            raise ValueError("level must be >= 1")
+        like_numpy = isinstance(x, np.ndarray)
+        x = self._prep_dec_input(x)
+        if list(x.shape) != self.sizes:
+            raise ValueError(f"input size {list(x.shape)} does not match the object's sizes {self.sizes}")
+        dev = self._dev(x if isinstance(x, torch.Tensor) else None)
+        xk = self._to_device_kernel_order(x, dev, self.NDIM)
+        is_c = xk.is_complex()
+        plan = self._plan(is_c, level, dev)
+        nb = num_bands(self.NDIM, level)
+        yk = torch.empty((nb,) + tuple(xk.shape), dtype=xk.dtype, device=dev)
+        with torch.cuda.device(dev):
+            plan.dec(xk.data_ptr(), yk.data_ptr(), level, _current_stream(dev))
+        return self._from_device(yk, like_numpy, dev)   # real in -> real out (nd_dwt_3D.m:189-192) by construction
+
+    # -- nd_dwt_3D.m:202-256 --
+    def rec(self, y):
+        like_numpy = isinstance(y, np.ndarray)
+        if y.ndim != self.NDIM + 1 or list(y.shape[:-1]) != self.sizes:
+            raise ValueError(f"coefficient array must have shape {self.sizes + ['bands']}")
+        level = self._level_from_bands(int(y.shape[-1]))
+        if num_bands(self.NDIM, level) != int(y.shape[-1]):
+            raise ValueError(f"{int(y.shape[-1])} bands is not a valid {self.NDIM}-D coefficient count")
+        dev = self._dev(y if isinstance(y, torch.Tensor) else None)
+        yk = self._to_device_kernel_order(y, dev, self.NDIM + 1)
+        plan = self._plan(yk.is_complex(), level, dev)
+        xk = torch.empty(tuple(yk.shape[1:]), dtype=yk.dtype, device=dev)
+        with torch.cuda.device(dev):
+            plan.rec(yk.data_ptr(), xk.data_ptr(), level, _current_stream(dev))
+        return self._from_device(xk, like_numpy, dev)
+
+    def _prep_dec_input(self, x):
+        return x
+
+
+class nd_dwt_1D(_NdDwtBase):
+    """Functions/nd_dwt_1D.m -- 1-D signal of length n; coefficients [n, 1+level]."""
+    NDIM = 1
+
+    def _check_sizes(self, sizes):
+        if len(sizes) != 1:
+            raise ValueError("1D array length must be a scalar")          # nd_dwt_1D.m:88
+
+    def _check_wname(self, wname):
+        if not isinstance(wname, str):
+            raise ValueError("Wavelet Name Must be a string")             # nd_dwt_1D.m:84
+        return [wname, wname]
+
+    def _level_from_bands(self, n):
+        return int(np.ceil(n - 1))                                        # nd_dwt_1D.m:213
+
+    def _prep_dec_input(self, x):
+        # row vectors are transposed (nd_dwt_1D.m:151-153); accept [n], [n,1] and [1,n]
+        if x.ndim == 2 and 1 in x.shape:
+            x = x.reshape(-1)
+        return x
+
+
+class nd_dwt_2D(_NdDwtBase):
+    """Functions/nd_dwt_2D.m -- coefficients [n1, n2, 4+3(level-1)]."""
+    NDIM = 2
+
+    def _check_sizes(self, sizes):
+        if len(sizes) != 2:
+            raise ValueError("The sizes vector must be length 2")
+
+    def _check_wname(self, wname):
+        if isinstance(wname, str):
+            return [wname, wname]
+        if len(wname) != 2:
+            raise ValueError("You must specify two filter names in a cell array of length 2, or a single string for the "
+                             "same filter to be used in all dimensions")
+        return list(wname)
+
+    def _level_from_bands(self, n):
+        return int(1 + (n - 4) / 3)                                       # nd_dwt_2D.m:215
+
+
+class nd_dwt_3D(_NdDwtBase):
+    """Functions/nd_dwt_3D.m -- coefficients [n1, n2, n3, 8+7(level-1)]."""
+    NDIM = 3
+
+    def _check_sizes(self, sizes):
+        if len(sizes) != 3:
+            raise ValueError("The sizes vector must be length 3")          # nd_dwt_3D.m:83
+
+    def _check_wname(self, wname):
+        if isinstance(wname, str):
+            return [wname, wname, wname]
+        if len(wname) != 3:                                               # nd_dwt_3D.m:94-96
+            raise ValueError("You must specify three filter names in a cell arrayof length 3, or a single string for "
+                             "the same filter to be used in all dimensions")
+        return list(wname)
+
+    def _level_from_bands(self, n):
+        return int(np.ceil(n / 8))                                        # nd_dwt_3D.m:217 (breaks for level >= 9, as there)
+
+
+class nd_dwt_4D(_NdDwtBase):
+    """Functions/nd_dwt_4D.m ('fft' method semantics) -- coefficients [n1, n2, n3, n4, 16+15(level-1)]."""
+    NDIM = 4
+
+    def _check_sizes(self, sizes):
+        if len(sizes) != 4:
+            raise ValueError("The sizes vector must be length 4")
+
+    def _check_wname(self, wname):
+        if isinstance(wname, str):
+            return [wname] * 4
+        if len(wname) != 4:
+            raise ValueError("You must specify four filter names in a cell array of length 4, or a single string for "
+                             "the same filter to be used in all dimensions")
+        return list(wname)
+
+    def _level_from_bands(self, n):
+        return int(1 + (n - 16) / 15)                                     # nd_dwt_4D.m:213

@@ -1,0 +1,614 @@
+// ndwt_api.hip -- plan, level loop, axis kernels and the C ABI of libndwt_hip.so (include/ndwt.h).
+//
+// Replaces, for the hot path, reference mex/nddwt.c (nd_dwt_dec :189-239, nd_dwt_rec :242-292 and
+// their 1-level forms :98-186) and the gateway mex/nd_dwt_mex.c:8-153.  No CPU fallback exists in
+// this library: every entry point runs HIP kernels or returns an error code.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ndwt.h"
+#include "ndwt_device.h"
+#include "ndwt_filters.h"
+#include "ndwt_fused.h"
+#include "ndwt_geom.h"
+
+using namespace ndwt;
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(NDWT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------ axis kernels
+template <typename T>
+__global__ __launch_bounds__(256) void axis_analysis_kernel(const T* __restrict__ in, T* __restrict__ lo, T* __restrict__ hi,
+                                                            const AxisTaps<T> tp, const AxisArgs<T> a) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (; idx < a.total; idx += step) axis_analysis_elem(idx, in, lo, hi, tp, a);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void axis_synthesis_kernel(const T* __restrict__ ain, const T* __restrict__ din,
+                                                             T* __restrict__ out, const AxisTaps<T> tp, const AxisArgs<T> a) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (; idx < a.total; idx += step) axis_synthesis_elem(idx, ain, din, out, tp, a);
+}
+
+// -------------------------------------------------------------------------------------------- plan
+struct ProfRec {
+    int kind;                          // NDWT_KERNEL_*
+    hipEvent_t start, stop;
+};
+
+struct ndwt_plan {
+    int ndim;
+    long long dims[NDWT_MAX_DIMS];
+    int order[NDWT_MAX_DIMS];          // K of dbK per axis
+    AxisFilter filt[NDWT_MAX_DIMS];
+    int dtype, complexity, l2, dilation, max_level, device, path;
+    size_t esize;                      // bytes per scalar
+    long long comp;                    // scalars per element (2 for interleaved complex)
+    long long vol;                     // scalars per band
+    void* approx[2];                   // approximation ping-pong between levels
+    void* tmp;                         // temporaries of the per-axis path / 4-D split
+    size_t tmp_bytes;
+    int target_blocks;                 // fused-kernel grid sizing
+    int force_zchunk;
+    // optional per-kernel timing with HIP events on the launch stream (bench.py's roofline figures)
+    int profiling;
+    std::vector<ProfRec>* prof;
+};
+
+static int ensure_tmp(ndwt_plan* p, size_t bytes) {
+    if (bytes <= p->tmp_bytes) return NDWT_OK;
+    if (p->tmp) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(p->tmp));
+        p->tmp = nullptr;
+        p->tmp_bytes = 0;
+    }
+    hipError_t e = hipMalloc(&p->tmp, bytes);
+    if (e != hipSuccess) return fail(NDWT_ERR_ALLOC, "hipMalloc(%zu bytes) for temporaries failed: %s", bytes, hipGetErrorString(e));
+    p->tmp_bytes = bytes;
+    return NDWT_OK;
+}
+
+static void prof_begin(const ndwt_plan* p, int kind, hipStream_t s) {
+    if (!p->profiling) return;
+    ProfRec r;
+    r.kind = kind;
+    if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
+    (void)hipEventRecord(r.start, s);
+    p->prof->push_back(r);
+}
+static void prof_end(const ndwt_plan* p, hipStream_t s) {
+    if (!p->profiling || p->prof->empty()) return;
+    (void)hipEventRecord(p->prof->back().stop, s);
+}
+
+static long long level_stride(const ndwt_plan* p, int lev) { return p->dilation == NDWT_DILATION_ATROUS ? (1LL << (lev - 1)) : 1LL; }
+
+// ------------------------------------------------------------------------------ one axis, one pass
+template <typename T>
+static int axis_pass(const ndwt_plan* p, bool synthesis, int axis, const long long* dims_cur, long long stride, bool wrap,
+                     const T* in0, const T* in1, T* out0, T* out1, hipStream_t s) {
+    const AxisFilter& f = p->filt[axis];
+    AxisTaps<T> tp;
+    tp.len = f.len;
+    for (int j = 0; j < kMaxTaps; ++j) { tp.lo[j] = 0; tp.hi[j] = 0; }
+    for (int j = 0; j < f.len; ++j) {
+        tp.lo[j] = (T)(synthesis ? f.syn_lo[j] : f.ana_lo[j]);
+        tp.hi[j] = (T)(synthesis ? f.syn_hi[j] : f.ana_hi[j]);
+    }
+    AxisArgs<T> a;
+    a.inner = p->comp;
+    for (int k = 0; k < axis; ++k) a.inner *= dims_cur[k];
+    a.outer = 1;
+    for (int k = axis + 1; k < p->ndim; ++k) a.outer *= dims_cur[k];
+    a.n = dims_cur[axis];
+    a.stride = stride;
+    a.left = (synthesis ? (long long)(f.len / 2) : (long long)(f.len / 2 - 1)) * stride;
+    a.wrap = wrap ? 1 : 0;
+    a.n_in = wrap ? a.n : a.n + (long long)(f.len - 1) * stride;
+    a.total = a.outer * a.n * a.inner;
+    if (a.total == 0) return NDWT_OK;
+    long long nb = (a.total + 255) / 256;
+    const long long cap = 256LL * 64;   // grid-stride beyond 64 blocks per CU
+    if (nb > cap) nb = cap;
+    prof_begin(p, synthesis ? NDWT_KERNEL_AXIS_SYNTHESIS : NDWT_KERNEL_AXIS_ANALYSIS, s);
+    if (synthesis)
+        hipLaunchKernelGGL(axis_synthesis_kernel<T>, dim3((unsigned)nb), dim3(256), 0, s, in0, in1, out0, tp, a);
+    else
+        hipLaunchKernelGGL(axis_analysis_kernel<T>, dim3((unsigned)nb), dim3(256), 0, s, in0, out0, out1, tp, a);
+    prof_end(p, s);
+    HIP_TRY(hipGetLastError());
+    return NDWT_OK;
+}
+
+// ---------------------------------------------------------------------- per-axis (general) levels
+// depth-first over the band tree, outermost axis first; temporaries: 2 volumes per tree depth
+template <typename T> struct GenericCtx {
+    const ndwt_plan* p;
+    long long stride;
+    bool slab;
+    long long dims_cur[NDWT_MAX_DIMS];
+    long long vol_cur;       // scalars per volume with the current dims
+    T* tmp;                  // 2*(ndim-1) volumes of vol_tmp scalars
+    long long vol_tmp;
+    hipStream_t s;
+};
+
+template <typename T> static int generic_analysis(GenericCtx<T>& c, int axis, const T* src, int prefix, T* const* out) {
+    const bool top = axis == c.p->ndim - 1;
+    const bool wrap = !(c.slab && top);
+    if (axis == 0) return axis_pass<T>(c.p, false, 0, c.dims_cur, c.stride, wrap, src, nullptr, out[prefix], out[prefix | 1], c.s);
+    T* lo = c.tmp + (long long)(2 * (axis - 1)) * c.vol_tmp;
+    T* hi = lo + c.vol_tmp;
+    int rc = axis_pass<T>(c.p, false, axis, c.dims_cur, c.stride, wrap, src, nullptr, lo, hi, c.s);
+    if (rc) return rc;
+    rc = generic_analysis(c, axis - 1, lo, prefix, out);
+    if (rc) return rc;
+    return generic_analysis(c, axis - 1, hi, prefix | (1 << axis), out);
+}
+
+template <typename T> static int generic_synthesis(GenericCtx<T>& c, int axis, int prefix, const T* const* in, T* dst) {
+    const bool top = axis == c.p->ndim - 1;
+    const bool wrap = !(c.slab && top);
+    if (axis == 0) return axis_pass<T>(c.p, true, 0, c.dims_cur, c.stride, wrap, in[prefix], in[prefix | 1], dst, nullptr, c.s);
+    T* a = c.tmp + (long long)(2 * (axis - 1)) * c.vol_tmp;
+    T* d = a + c.vol_tmp;
+    int rc = generic_synthesis(c, axis - 1, prefix, in, a);
+    if (rc) return rc;
+    rc = generic_synthesis(c, axis - 1, prefix | (1 << axis), in, d);
+    if (rc) return rc;
+    return axis_pass<T>(c.p, true, axis, c.dims_cur, c.stride, wrap, a, d, dst, nullptr, c.s);
+}
+
+// ------------------------------------------------------------------------------------ fused levels
+static bool fused3_eligible(const ndwt_plan* p, long long stride, int* Lp_out) {
+    if (p->path != NDWT_PATH_AUTO || p->complexity != NDWT_REAL || stride != 1 || p->ndim < 3) return false;
+    int Lp = 2;
+    for (int a = 0; a < 3; ++a) Lp = p->filt[a].len > Lp ? p->filt[a].len : Lp;
+    if (Lp > 12) return false;   // instantiated tap lengths: 2..12 (db1..db6); longer filters take the per-axis path
+    long long nbatch = p->ndim == 4 ? p->dims[3] + 64 : 1;
+    if (!fused3_fits(p->dims[0], p->dims[1], p->dims[2] + 64, nbatch)) return false;
+    *Lp_out = Lp;
+    return true;
+}
+
+static FusedTapsD fused_taps(const ndwt_plan* p, int Lp, bool synthesis) {
+    FusedTapsD t;
+    t.Lp = Lp;
+    for (int a = 0; a < 3; ++a) {
+        const AxisFilter& f = p->filt[a];
+        pad_taps(synthesis ? f.syn_lo : f.ana_lo, f.len, Lp, t.lo[a]);
+        pad_taps(synthesis ? f.syn_hi : f.ana_hi, f.len, Lp, t.hi[a]);
+    }
+    return t;
+}
+
+template <typename T> static bool aligned_vec4(const void* ptr) { return ((uintptr_t)ptr % (4 * sizeof(T))) == 0; }
+
+template <typename T> static int launch3(bool inverse, const Fused3Args<T>& a, const FusedTapsD& t, bool vec4, hipStream_t s);
+template <> int launch3<float>(bool inverse, const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, hipStream_t s) {
+    return inverse ? launch_inv3_f32(a, t, vec4, s) : launch_fwd3_f32(a, t, vec4, s);
+}
+template <> int launch3<double>(bool inverse, const Fused3Args<double>& a, const FusedTapsD& t, bool vec4, hipStream_t s) {
+    return inverse ? launch_inv3_f64(a, t, vec4, s) : launch_fwd3_f64(a, t, vec4, s);
+}
+
+// one fused 3-D launch over `nbatch` volumes. n3 = output planes; z_wrap=false: inputs carry the z halo
+template <typename T>
+static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* in, T* const* out, long long n3, long long nbatch,
+                      long long in_bstride, long long out_bstride, bool z_wrap, hipStream_t s) {
+    Fused3Args<T> a;
+    memset(&a, 0, sizeof a);
+    a.n1 = (int)p->dims[0];
+    a.n2 = (int)p->dims[1];
+    a.n3 = (int)n3;
+    a.nbatch = (int)nbatch;
+    a.in_bstride = in_bstride;
+    a.out_bstride = out_bstride;
+    a.z_wrap = z_wrap ? 1 : 0;
+    bool vec4 = (a.n1 % 4 == 0) && (in_bstride % 4 == 0) && (out_bstride % 4 == 0);
+    const int nin = inverse ? 8 : 1, nout = inverse ? 1 : 8;
+    for (int b = 0; b < nin; ++b) { a.in[b] = in[b]; vec4 = vec4 && aligned_vec4<T>(in[b]); }
+    for (int b = 0; b < nout; ++b) { a.out[b] = out[b]; vec4 = vec4 && aligned_vec4<T>(out[b]); }
+    fused3_geometry(a, Fused3Tile<T>::TX, Fused3Tile<T>::TY, Lp, p->target_blocks, p->force_zchunk);
+    FusedTapsD t = fused_taps(p, Lp, inverse);
+    prof_begin(p, inverse ? NDWT_KERNEL_FUSED_SYNTHESIS : NDWT_KERNEL_FUSED_ANALYSIS, s);
+    int rc = launch3<T>(inverse, a, t, vec4, s);
+    prof_end(p, s);
+    if (rc == -1) return fail(NDWT_ERR_UNSUPPORTED, "no fused kernel instantiated for tap length %d", Lp);
+    if (rc != 0) return fail(NDWT_ERR_HIP, "fused kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return NDWT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ levels
+// analysis of one level: in (vol scalars, + halo planes on the outer axis in slab mode) -> 2^d bands
+template <typename T>
+static int analysis_level(ndwt_plan* p, const T* in, T* const* out, long long stride, bool slab, hipStream_t s) {
+    const int d = p->ndim;
+    const AxisFilter& ftop = p->filt[d - 1];
+    const long long n_top = p->dims[d - 1];
+    const long long n_top_in = slab ? n_top + (long long)(ftop.len - 1) * stride : n_top;
+    const long long vol_in = p->vol / n_top * n_top_in;
+    int Lp = 0;
+    // slab mode hands over exactly (L_top-1) halo planes: the fused kernel marches with the padded length
+    if (fused3_eligible(p, stride, &Lp) && !(slab && d == 3 && ftop.len != Lp)) {
+        const long long vol3 = p->dims[0] * p->dims[1] * p->dims[2];
+        if (d == 3) {
+            const T* ins[8] = {in};
+            return fused3_run<T>(p, false, Lp, ins, out, p->dims[2], 1, vol_in, p->vol, !slab, s);
+        }
+        // d == 4: outer axis per-axis (1 -> 2), then the fused 3-D kernel on both halves, batched over n4
+        int rc = ensure_tmp(p, (size_t)(2 * p->vol) * sizeof(T));
+        if (rc) return rc;
+        T* lo = (T*)p->tmp;
+        T* hi = lo + p->vol;
+        rc = axis_pass<T>(p, false, 3, p->dims, stride, !slab, in, nullptr, lo, hi, s);
+        if (rc) return rc;
+        const T* ins_lo[8] = {lo};
+        const T* ins_hi[8] = {hi};
+        rc = fused3_run<T>(p, false, Lp, ins_lo, out, p->dims[2], p->dims[3], vol3, vol3, true, s);
+        if (rc) return rc;
+        return fused3_run<T>(p, false, Lp, ins_hi, out + 8, p->dims[2], p->dims[3], vol3, vol3, true, s);
+    }
+    GenericCtx<T> c;
+    c.p = p; c.stride = stride; c.slab = slab; c.s = s;
+    for (int k = 0; k < d; ++k) c.dims_cur[k] = p->dims[k];
+    c.vol_cur = p->vol;
+    c.vol_tmp = p->vol;
+    if (d > 1) {
+        int rc = ensure_tmp(p, (size_t)(2 * (d - 1)) * (size_t)c.vol_tmp * sizeof(T));
+        if (rc) return rc;
+    }
+    c.tmp = (T*)p->tmp;
+    return generic_analysis<T>(c, d - 1, in, 0, out);
+}
+
+template <typename T>
+static int synthesis_level(ndwt_plan* p, const T* const* in, T* out, long long stride, bool slab, hipStream_t s) {
+    const int d = p->ndim;
+    const AxisFilter& ftop = p->filt[d - 1];
+    const long long n_top = p->dims[d - 1];
+    const long long n_top_in = slab ? n_top + (long long)(ftop.len - 1) * stride : n_top;
+    const long long vol_in = p->vol / n_top * n_top_in;
+    int Lp = 0;
+    if (fused3_eligible(p, stride, &Lp) && !(slab && d == 3 && ftop.len != Lp)) {
+        const long long vol3 = p->dims[0] * p->dims[1] * p->dims[2];
+        if (d == 3) {
+            T* outs[8] = {out};
+            return fused3_run<T>(p, true, Lp, in, outs, p->dims[2], 1, vol_in, p->vol, !slab, s);
+        }
+        int rc = ensure_tmp(p, (size_t)(2 * vol_in) * sizeof(T));
+        if (rc) return rc;
+        T* a = (T*)p->tmp;
+        T* dd = a + vol_in;
+        T* outs_a[8] = {a};
+        T* outs_d[8] = {dd};
+        rc = fused3_run<T>(p, true, Lp, in, outs_a, p->dims[2], n_top_in, vol3, vol3, true, s);
+        if (rc) return rc;
+        rc = fused3_run<T>(p, true, Lp, in + 8, outs_d, p->dims[2], n_top_in, vol3, vol3, true, s);
+        if (rc) return rc;
+        return axis_pass<T>(p, true, 3, p->dims, stride, !slab, a, dd, out, nullptr, s);
+    }
+    GenericCtx<T> c;
+    c.p = p; c.stride = stride; c.slab = slab; c.s = s;
+    for (int k = 0; k < d; ++k) c.dims_cur[k] = p->dims[k];
+    c.dims_cur[d - 1] = n_top_in;          // inner axes run on the haloed slab; the outer pass trims it
+    c.vol_cur = vol_in;
+    c.vol_tmp = vol_in;
+    if (d > 1) {
+        int rc = ensure_tmp(p, (size_t)(2 * (d - 1)) * (size_t)c.vol_tmp * sizeof(T));
+        if (rc) return rc;
+    }
+    c.tmp = (T*)p->tmp;
+    // the outermost pass must see dims_cur[d-1] == local length
+    if (d == 1) {
+        c.dims_cur[0] = n_top;
+        return generic_synthesis<T>(c, 0, 0, in, out);
+    }
+    T* a = c.tmp + (long long)(2 * (d - 2)) * c.vol_tmp;
+    T* dd = a + c.vol_tmp;
+    int rc = generic_synthesis<T>(c, d - 2, 0, in, a);
+    if (rc) return rc;
+    rc = generic_synthesis<T>(c, d - 2, 1 << (d - 1), in, dd);
+    if (rc) return rc;
+    c.dims_cur[d - 1] = n_top;
+    return axis_pass<T>(p, true, d - 1, c.dims_cur, stride, !slab, a, dd, out, nullptr, s);
+}
+
+// --------------------------------------------------------------------------------- multi-level
+// band bookkeeping of nddwt.c:210,225-234 / nd_dwt_3D.m:178-186: level `lev` (1 = finest) stores its
+// 2^d-1 detail bands at [1 + (2^d-1)(level-lev), ...); the coarsest approximation is band 0.  Unlike
+// the reference there is no cat() copy (nd_dwt_3D.m:184) and no in-place overwrite of the input.
+template <typename T> static int dec_impl(ndwt_plan* p, const T* x, T* y, int level, hipStream_t s) {
+    const int nb = 1 << p->ndim;
+    const T* cur = x;
+    for (int lev = 1; lev <= level; ++lev) {
+        T* out[16];
+        out[0] = (lev == level) ? y : (T*)p->approx[(lev - 1) & 1];
+        for (int b = 1; b < nb; ++b) out[b] = y + (long long)(1 + (nb - 1) * (level - lev) + (b - 1)) * p->vol;
+        int rc = analysis_level<T>(p, cur, out, level_stride(p, lev), false, s);
+        if (rc) return rc;
+        cur = out[0];
+    }
+    return NDWT_OK;
+}
+
+template <typename T> static int rec_impl(ndwt_plan* p, const T* y, T* x, int level, hipStream_t s) {
+    const int nb = 1 << p->ndim;
+    const T* prev = y;   // band 0
+    for (int ind = 1; ind <= level; ++ind) {
+        const int lev = level - ind + 1;
+        const T* in[16];
+        in[0] = prev;
+        for (int b = 1; b < nb; ++b) in[b] = y + (long long)(1 + (nb - 1) * (level - lev) + (b - 1)) * p->vol;
+        T* dst = (lev == 1) ? x : (T*)p->approx[(ind - 1) & 1];
+        int rc = synthesis_level<T>(p, in, dst, level_stride(p, lev), false, s);
+        if (rc) return rc;
+        prev = dst;
+    }
+    return NDWT_OK;
+}
+
+static int check_level(const ndwt_plan* p, int level) {
+    if (!p) return fail(NDWT_ERR_INVALID_ARG, "null plan");
+    if (level < 1 || level > p->max_level)
+        return fail(NDWT_ERR_INVALID_ARG, "level %d outside 1..max_level=%d of this plan", level, p->max_level);
+    if (p->dilation == NDWT_DILATION_ATROUS) {
+        for (int a = 0; a < p->ndim; ++a) {
+            long long span = (long long)(p->filt[a].len - 1) * (1LL << (level - 1)) + 1;
+            (void)span;   // spans longer than the axis wrap several times; the kernels handle it
+        }
+    }
+    return NDWT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+int ndwt_wave_filters(const char* wname, double* lo_d, double* hi_d, int* len) {
+    const int K = parse_wavelet(wname);
+    if (!K) return fail(NDWT_ERR_UNKNOWN_WAVELET, "Unknown Wavelet Name");
+    if (!lo_d || !hi_d || !len) return fail(NDWT_ERR_INVALID_ARG, "null output pointer");
+    wave_filters(K, lo_d, hi_d);
+    *len = 2 * K;
+    return NDWT_OK;
+}
+
+int64_t ndwt_num_bands(int ndim, int level) {
+    if (ndim < 1 || ndim > NDWT_MAX_DIMS || level < 1) return -1;
+    return (int64_t)(1 << ndim) + (int64_t)((1 << ndim) - 1) * (level - 1);
+}
+
+int ndwt_level_from_bands(int ndim, int64_t bands) {
+    if (ndim < 1 || ndim > NDWT_MAX_DIMS) return -1;
+    const int64_t nb = 1 << ndim;
+    if (bands < nb || (bands - nb) % (nb - 1) != 0) return -1;
+    return (int)(1 + (bands - nb) / (nb - 1));
+}
+
+int ndwt_plan_create(ndwt_plan** plan, int ndim, const int64_t* dims, const char* const* wnames, int dtype, int complexity,
+                     int pres_l2_norm, int dilation, int max_level, int device) {
+    if (!plan) return fail(NDWT_ERR_INVALID_ARG, "null plan pointer");
+    *plan = nullptr;
+    if (ndim < 1 || ndim > NDWT_MAX_DIMS) return fail(NDWT_ERR_INVALID_ARG, "ndim must be 1..4");
+    if (!dims || !wnames) return fail(NDWT_ERR_INVALID_ARG, "null dims/wnames");
+    if (dtype != NDWT_F32 && dtype != NDWT_F64) return fail(NDWT_ERR_INVALID_ARG, "dtype must be NDWT_F32 or NDWT_F64");
+    if (complexity != NDWT_REAL && complexity != NDWT_COMPLEX_INTERLEAVED) return fail(NDWT_ERR_INVALID_ARG, "bad complexity");
+    if (dilation != NDWT_DILATION_REFERENCE && dilation != NDWT_DILATION_ATROUS) return fail(NDWT_ERR_INVALID_ARG, "bad dilation mode");
+    if (max_level < 1 || max_level > 30) return fail(NDWT_ERR_INVALID_ARG, "max_level must be 1..30");
+    ndwt_plan* p = new ndwt_plan();
+    memset(p, 0, sizeof *p);
+    p->ndim = ndim;
+    p->dtype = dtype;
+    p->complexity = complexity;
+    p->l2 = pres_l2_norm ? 1 : 0;
+    p->dilation = dilation;
+    p->max_level = max_level;
+    p->device = device;
+    p->path = NDWT_PATH_AUTO;
+    p->esize = dtype == NDWT_F32 ? 4 : 8;
+    p->comp = complexity == NDWT_COMPLEX_INTERLEAVED ? 2 : 1;
+    p->target_blocks = 2048;
+    p->prof = new std::vector<ProfRec>();
+    static const char* ordn[4] = {"First", "Second", "Third", "Fourth"};
+    p->vol = p->comp;
+    for (int a = 0; a < ndim; ++a) {
+        if (dims[a] < 1) { delete p->prof; delete p; return fail(NDWT_ERR_INVALID_ARG, "dims[%d] must be >= 1", a); }
+        const int K = parse_wavelet(wnames[a]);
+        if (!K) { delete p->prof; delete p; return fail(NDWT_ERR_UNKNOWN_WAVELET, "Unknown Wavelet Name"); }
+        p->dims[a] = dims[a];
+        p->order[a] = K;
+        p->filt[a] = make_axis_filter(K, p->l2 != 0);
+        if (p->filt[a].len > dims[a]) {   // nd_dwt_3D.m:277-286
+            delete p->prof;
+            delete p;
+            return fail(NDWT_ERR_FILTER_TOO_LONG, "%s Dimension of Data is shorter than the wavelet filter being used", ordn[a]);
+        }
+        p->vol *= dims[a];
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        delete p->prof;
+        delete p;
+        return fail(NDWT_ERR_NO_DEVICE, "no usable HIP device (requested %d of %d): this engine has no CPU path", device, ndev);
+    }
+    if (hipSetDevice(device) != hipSuccess) { delete p->prof; delete p; return fail(NDWT_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device); }
+    const int napprox = max_level >= 3 ? 2 : (max_level == 2 ? 1 : 0);
+    for (int i = 0; i < napprox; ++i) {
+        hipError_t e = hipMalloc(&p->approx[i], (size_t)p->vol * p->esize);
+        if (e != hipSuccess) {
+            ndwt_plan_destroy(p);
+            return fail(NDWT_ERR_ALLOC, "hipMalloc of the approximation scratch failed: %s", hipGetErrorString(e));
+        }
+    }
+    *plan = p;
+    return NDWT_OK;
+}
+
+int ndwt_plan_destroy(ndwt_plan* p) {
+    if (!p) return NDWT_OK;
+    (void)hipSetDevice(p->device);
+    for (int i = 0; i < 2; ++i)
+        if (p->approx[i]) (void)hipFree(p->approx[i]);
+    if (p->tmp) (void)hipFree(p->tmp);
+    if (p->prof) {
+        for (auto& r : *p->prof) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+        delete p->prof;
+    }
+    delete p;
+    return NDWT_OK;
+}
+
+int ndwt_plan_set_profiling(ndwt_plan* p, int enable) {
+    if (!p) return fail(NDWT_ERR_INVALID_ARG, "null plan");
+    p->profiling = enable ? 1 : 0;
+    return NDWT_OK;
+}
+
+// sums (and clears) the event records of one kernel kind; synchronises the device
+int ndwt_plan_get_profile(ndwt_plan* p, int kind, double* total_ms, int64_t* launches) {
+    if (!p || !total_ms || !launches) return fail(NDWT_ERR_INVALID_ARG, "bad arguments");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipDeviceSynchronize());
+    double tot = 0;
+    int64_t n = 0;
+    std::vector<ProfRec> keep;
+    for (auto& r : *p->prof) {
+        if (r.kind != kind) { keep.push_back(r); continue; }
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) { tot += ms; ++n; }
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
+    }
+    p->prof->swap(keep);
+    *total_ms = tot;
+    *launches = n;
+    return NDWT_OK;
+}
+
+int ndwt_plan_set_path(ndwt_plan* p, int path) {
+    if (!p || (path != NDWT_PATH_AUTO && path != NDWT_PATH_GENERIC)) return fail(NDWT_ERR_INVALID_ARG, "bad plan/path");
+    p->path = path;
+    return NDWT_OK;
+}
+
+// test/tuning hook: grid sizing of the fused kernels (0 = default)
+int ndwt_plan_set_tuning(ndwt_plan* p, int target_blocks, int force_zchunk) {
+    if (!p) return fail(NDWT_ERR_INVALID_ARG, "null plan");
+    p->target_blocks = target_blocks > 0 ? target_blocks : 2048;
+    p->force_zchunk = force_zchunk > 0 ? force_zchunk : 0;
+    return NDWT_OK;
+}
+
+int ndwt_plan_describe(const ndwt_plan* p, char* buf, int buflen) {
+    if (!p || !buf || buflen < 1) return fail(NDWT_ERR_INVALID_ARG, "bad arguments");
+    int Lp = 0;
+    const char* s = "axis";
+    if (fused3_eligible(p, 1, &Lp)) s = p->ndim == 3 ? "fused3d" : "axis+fused3d";
+    snprintf(buf, (size_t)buflen, "%s", s);
+    return NDWT_OK;
+}
+
+int ndwt_dec(ndwt_plan* p, const void* x, void* y, int level, void* stream) {
+    int rc = check_level(p, level);
+    if (rc) return rc;
+    if (!x || !y) return fail(NDWT_ERR_INVALID_ARG, "null data pointer");
+    HIP_TRY(hipSetDevice(p->device));
+    hipStream_t s = (hipStream_t)stream;
+    return p->dtype == NDWT_F32 ? dec_impl<float>(p, (const float*)x, (float*)y, level, s)
+                                : dec_impl<double>(p, (const double*)x, (double*)y, level, s);
+}
+
+int ndwt_rec(ndwt_plan* p, const void* y, void* x, int level, void* stream) {
+    int rc = check_level(p, level);
+    if (rc) return rc;
+    if (!x || !y) return fail(NDWT_ERR_INVALID_ARG, "null data pointer");
+    HIP_TRY(hipSetDevice(p->device));
+    hipStream_t s = (hipStream_t)stream;
+    return p->dtype == NDWT_F32 ? rec_impl<float>(p, (const float*)y, (float*)x, level, s)
+                                : rec_impl<double>(p, (const double*)y, (double*)x, level, s);
+}
+
+static int host_roundtrip(ndwt_plan* p, bool inverse, const void* src, void* dst, int level) {
+    int rc = check_level(p, level);
+    if (rc) return rc;
+    if (!src || !dst) return fail(NDWT_ERR_INVALID_ARG, "null data pointer");
+    HIP_TRY(hipSetDevice(p->device));
+    const size_t bx = (size_t)p->vol * p->esize;
+    const size_t by = bx * (size_t)ndwt_num_bands(p->ndim, level);
+    void *dx = nullptr, *dy = nullptr;
+    if (hipMalloc(&dx, bx) != hipSuccess || hipMalloc(&dy, by) != hipSuccess) {
+        if (dx) (void)hipFree(dx);
+        return fail(NDWT_ERR_ALLOC, "hipMalloc of staging buffers (%zu + %zu bytes) failed", bx, by);
+    }
+    hipError_t e = hipMemcpy(inverse ? dy : dx, src, inverse ? by : bx, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = inverse ? ndwt_rec(p, dy, dx, level, nullptr) : ndwt_dec(p, dx, dy, level, nullptr);
+        if (rc == NDWT_OK) e = hipMemcpy(dst, inverse ? dx : dy, inverse ? bx : by, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(dx);
+    (void)hipFree(dy);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(NDWT_ERR_HIP, "staging copy failed: %s", hipGetErrorString(e));
+    return NDWT_OK;
+}
+
+int ndwt_dec_host(ndwt_plan* p, const void* x, void* y, int level) { return host_roundtrip(p, false, x, y, level); }
+int ndwt_rec_host(ndwt_plan* p, const void* y, void* x, int level) { return host_roundtrip(p, true, y, x, level); }
+
+int ndwt_slab_halo(const ndwt_plan* p, int stride, int64_t* ab, int64_t* aa, int64_t* sb, int64_t* sa) {
+    if (!p || stride < 1) return fail(NDWT_ERR_INVALID_ARG, "bad plan/stride");
+    const int L = p->filt[p->ndim - 1].len;
+    if (ab) *ab = (int64_t)(L / 2 - 1) * stride;
+    if (aa) *aa = (int64_t)(L / 2) * stride;
+    if (sb) *sb = (int64_t)(L / 2) * stride;
+    if (sa) *sa = (int64_t)(L / 2 - 1) * stride;
+    return NDWT_OK;
+}
+
+int ndwt_analysis_level_slab(ndwt_plan* p, const void* in, void* const* out, int stride, void* stream) {
+    if (!p || !in || !out || stride < 1) return fail(NDWT_ERR_INVALID_ARG, "bad arguments");
+    HIP_TRY(hipSetDevice(p->device));
+    hipStream_t s = (hipStream_t)stream;
+    return p->dtype == NDWT_F32 ? analysis_level<float>(p, (const float*)in, (float* const*)out, stride, true, s)
+                                : analysis_level<double>(p, (const double*)in, (double* const*)out, stride, true, s);
+}
+
+int ndwt_synthesis_level_slab(ndwt_plan* p, const void* const* in, void* out, int stride, void* stream) {
+    if (!p || !in || !out || stride < 1) return fail(NDWT_ERR_INVALID_ARG, "bad arguments");
+    HIP_TRY(hipSetDevice(p->device));
+    hipStream_t s = (hipStream_t)stream;
+    return p->dtype == NDWT_F32 ? synthesis_level<float>(p, (const float* const*)in, (float*)out, stride, true, s)
+                                : synthesis_level<double>(p, (const double* const*)in, (double*)out, stride, true, s);
+}
+
+const char* ndwt_last_error(void) { return g_last_error.c_str(); }
+const char* ndwt_version(void) { return "ndwt-hip 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ndwt_device.h"
+#include "ndwt_fused_tile.h"
 
 namespace ndwt {
 
@@ -13,11 +14,6 @@ struct FusedTapsD {       // per axis (0 = x, 1 = y, 2 = z), zero-padded to Lp, 
     double lo[3][kMaxTaps];
     double hi[3][kMaxTaps];
 };
-
-// tile shape of the fused 3-D kernels (shared by launch geometry and kernels)
-template <typename T> struct Fused3Tile;
-template <> struct Fused3Tile<float>  { static constexpr int TX = 64, TY = 16, NT = 256, RY = 4; };
-template <> struct Fused3Tile<double> { static constexpr int TX = 64, TY = 8,  NT = 256, RY = 4; };
 
 int launch_fwd3_f32(const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, hipStream_t s);
 int launch_inv3_f32(const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, hipStream_t s);

@@ -11,6 +11,7 @@
 #define NDWT_HOST_EMU 1
 #include "ndwt_device.h"
 #include "ndwt_geom.h"
+#include "ndwt_fused_tile.h"
 
 namespace {
 
@@ -41,15 +42,22 @@ int run(ndwt::Fused3Args<T>& a, const double* lo, const double* hi) {
     return 0;
 }
 
-template <typename T, template <typename, int, int, int, int, int, bool> class KIND, int TX, int TY, int NT, int RY>
+template <typename T, template <typename, int, int, int, int, int, bool> class KIND, int TX, int TY, int NT, int RY, bool ALL>
 int dispatch(int Lp, int vec4, ndwt::Fused3Args<T>& a, const double* lo, const double* hi) {
 #define CASE(LL)                                                              \
     case LL:                                                                  \
         return vec4 ? run<KIND<T, LL, TX, TY, NT, RY, true>, T>(a, lo, hi)    \
                     : run<KIND<T, LL, TX, TY, NT, RY, false>, T>(a, lo, hi);
-    switch (Lp) {
-        CASE(2) CASE(4) CASE(6) CASE(8) CASE(12)
-        default: return -1;
+    if constexpr (ALL) {
+        switch (Lp) {
+            CASE(2) CASE(4) CASE(6) CASE(8) CASE(12)
+            default: return -1;
+        }
+    } else {   // the production tile shape is emulated for db4 only (build time)
+        switch (Lp) {
+            CASE(8)
+            default: return -1;
+        }
     }
 #undef CASE
 }
@@ -75,12 +83,13 @@ int emu3(int inverse, int Lp, int vec4, const T* in, T* out, int n1, int n2, int
     }
     if (small_tile) {   // a second tile shape exercises different item/lane mappings
         ndwt::fused3_geometry(a, 16, 8, Lp, 2048, zchunk);
-        return inverse ? dispatch<T, ndwt::Inv3, 16, 8, 64, 2>(Lp, vec4, a, lo, hi)
-                       : dispatch<T, ndwt::Fwd3, 16, 8, 64, 2>(Lp, vec4, a, lo, hi);
+        return inverse ? dispatch<T, ndwt::Inv3, 16, 8, 64, 2, true>(Lp, vec4, a, lo, hi)
+                       : dispatch<T, ndwt::Fwd3, 16, 8, 64, 2, true>(Lp, vec4, a, lo, hi);
     }
-    ndwt::fused3_geometry(a, 64, 16, Lp, 2048, zchunk);
-    return inverse ? dispatch<T, ndwt::Inv3, 64, 16, 256, 4>(Lp, vec4, a, lo, hi)
-                   : dispatch<T, ndwt::Fwd3, 64, 16, 256, 4>(Lp, vec4, a, lo, hi);
+    typedef ndwt::Fused3Tile<T> P;   // the tile shape the library launches
+    ndwt::fused3_geometry(a, P::TX, P::TY, Lp, 2048, zchunk);
+    return inverse ? dispatch<T, ndwt::Inv3, P::TX, P::TY, P::NT, P::RY, false>(Lp, vec4, a, lo, hi)
+                   : dispatch<T, ndwt::Fwd3, P::TX, P::TY, P::NT, P::RY, false>(Lp, vec4, a, lo, hi);
 }
 
 }  // namespace

@@ -58,7 +58,7 @@ CASES = [
     ((16, 9, 7), ("db1", "db3", "db2"), True, 0, True),
     ((13, 10, 9), ("db2", "db2", "db2"), False, 4, True),
     ((20, 17, 12), ("db4", "db4", "db4"), True, 5, True),
-    ((68, 18, 9), ("db4", "db4", "db4"), True, 0, False),
+    ((68, 18, 9), ("db4", "db4", "db4"), True, 0, False),       # production tile shape (db4 only)
     ((70, 19, 10), ("db2", "db1", "db4"), False, 6, False),
 ]
 

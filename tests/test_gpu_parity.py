@@ -1,0 +1,264 @@
+"""GPU parity tests: the HIP engine (through the C ABI and the nd_dwt_{1,2,3,4}D mirror classes) against the
+CPU oracle, the golden fixtures and -- at full size -- size-independent properties.
+
+Tolerances (BASELINE.md section 2 / SURVEY.md 8c): fp64 <= 1e-12 relative to max|c|; fp32 <= 2e-6 relative to
+max|c|; fwd+inv round trip < 1e-6 as a relative l2 norm.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ndwt_amd as ndwt
+import ndwt_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+CLS = {1: ndwt.nd_dwt_1D, 2: ndwt.nd_dwt_2D, 3: ndwt.nd_dwt_3D, 4: ndwt.nd_dwt_4D} if True else {}
+TOL = {"double": 1e-12, "single": 2e-6}
+
+
+def _cls(d):
+    return {1: ndwt.nd_dwt_1D, 2: ndwt.nd_dwt_2D, 3: ndwt.nd_dwt_3D, 4: ndwt.nd_dwt_4D}[d]
+
+
+def _relerr(got, want):
+    return float(np.abs(np.asarray(got) - want).max() / max(np.abs(want).max(), 1e-300))
+
+
+def _colmajor_gpu(a, dtype):
+    """numpy MATLAB-shaped array -> GPU tensor of the same shape, column-major memory."""
+    t = torch.from_numpy(np.ascontiguousarray(np.transpose(a))).cuda()
+    if a.dtype.kind == "c":
+        t = t.to(torch.complex64 if dtype == "single" else torch.complex128)
+    else:
+        t = t.to(torch.float32 if dtype == "single" else torch.float64)
+    return t.permute(*reversed(range(t.dim())))
+
+
+def test_extension_is_loaded_and_reports_fused_path():
+    assert os.path.exists(ndwt.LIB_PATH)
+    w = ndwt.nd_dwt_3D("db4", [64, 64, 64], precision="single")
+    x = torch.randn(64, 64, 64, device="cuda")
+    w.dec(x, 1)
+    assert list(w._plans.values())[0].describe() == "fused3d"
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+@pytest.mark.parametrize("precision", ["double", "single"])
+@pytest.mark.parametrize("generic", [False, True])
+def test_golden_fixtures(path, precision, generic):
+    g = np.load(path)
+    sizes, level, wn = [int(s) for s in g["sizes"]], int(g["level"]), [str(w) for w in g["wname"]]
+    d = len(sizes)
+    wname = wn[0] if d == 1 else wn
+    for tag, l2s in (("r", (0, 1)), ("c", (1,))):
+        for l2 in l2s:
+            w = _cls(d)(wname, sizes, "pres_l2_norm", l2, "precision", precision)
+            x = _colmajor_gpu(g[f"x_{tag}"], precision)
+            y = w.dec(x, level)
+            for p in w._plans.values():
+                p.set_path(generic)
+            y = w.dec(x, level)
+            assert tuple(y.shape) == tuple(sizes) + (orc.num_bands(d, level),)
+            assert y.is_complex() == (tag == "c")
+            assert _relerr(y.cpu().numpy(), g[f"y_{tag}_l2{l2}"]) <= TOL[precision]
+            r = w.rec(_colmajor_gpu(g[f"c_{tag}"], precision))
+            assert _relerr(r.cpu().numpy(), g[f"rec_{tag}_l2{l2}"]) <= TOL[precision]
+    # a-trous mode (per-axis kernels with runtime tap stride)
+    w = _cls(d)(wname, sizes, "precision", precision, "dilation", "atrous")
+    y = w.dec(_colmajor_gpu(g["x_r"], precision), level)
+    assert _relerr(y.cpu().numpy(), g["y_r_l20_atrous"]) <= TOL[precision]
+    r = w.rec(_colmajor_gpu(g["c_r"], precision))
+    assert _relerr(r.cpu().numpy(), g["rec_r_l20_atrous"]) <= TOL[precision]
+
+
+# the reference's own test configurations (Test/nddwt{1,2,3,4}D_test.m:5-11): complex randn input, dec -> rec
+REF_TESTS = [
+    (1, [54321], "db1", 4, 0),
+    (2, [264, 264], ["db1", "db3"], 1, 1),
+    (3, [164, 64, 40], ["db1", "db3", "db1"], 1, 1),
+    (4, [64, 64, 20, 10], ["db1", "db3", "db1", "db1"], 1, 1),
+]
+
+
+@pytest.mark.parametrize("d,sizes,wname,level,l2", REF_TESTS, ids=["1D", "2D", "3D", "4D"])
+@pytest.mark.parametrize("precision", ["double", "single"])
+def test_reference_test_scripts(d, sizes, wname, level, l2, precision):
+    rng = np.random.default_rng(10 + d)
+    x = rng.standard_normal(sizes) + 1j * rng.standard_normal(sizes)
+    w = _cls(d)(wname, sizes[0] if d == 1 else sizes, "pres_l2_norm", l2, "precision", precision)
+    xg = _colmajor_gpu(x, precision)
+    y = w.dec(xg, level)
+    r = w.rec(y)
+    want = orc.NdDwtMat(wname, sizes, l2).dec(x, level)
+    assert _relerr(y.cpu().numpy(), want) <= TOL[precision]                                    # (C) backends agree
+    assert y.dtype == (torch.complex64 if precision == "single" else torch.complex128)         # (D) class follows precision
+    xn = np.linalg.norm(x)
+    if l2:
+        assert abs(float(torch.linalg.vector_norm(y)) - xn) <= (1e-5 if precision == "single" else 1e-11) * xn   # (B)
+    err = float(torch.linalg.vector_norm(r - xg)) / xn
+    assert err < (1e-6 if precision == "single" else 1e-13)                                    # (A)
+
+
+RANDOM = [
+    # d, sizes, wavelets, level
+    (1, [97], "db5", 3),
+    (1, [4096], "db2", 3),                       # BASELINE config 1 shape (fp64 db2 3 levels)
+    (2, [70, 45], ["db2", "db4"], 3),
+    (2, [128, 64], ["db4", "db4"], 2),
+    (3, [37, 29, 23], ["db3", "db1", "db2"], 2),
+    (3, [72, 40, 33], ["db4", "db4", "db4"], 3),
+    (3, [64, 32, 48], ["db6", "db6", "db6"], 2),
+    (3, [40, 40, 40], ["db8", "db2", "db2"], 2),  # longer than the fused instantiations -> per-axis path
+    (4, [12, 9, 10, 11], ["db2", "db1", "db3", "db2"], 2),
+    (4, [32, 32, 16, 16], ["db4", "db4", "db4", "db4"], 2),   # example_nd_dwt_4D.m:5 size
+]
+
+
+@pytest.mark.parametrize("d,sizes,wname,level", RANDOM)
+@pytest.mark.parametrize("precision", ["double", "single"])
+@pytest.mark.parametrize("l2", [0, 1])
+def test_random_shapes_against_oracle(d, sizes, wname, level, precision, l2):
+    rng = np.random.default_rng(20 + d)
+    x = rng.standard_normal(sizes)
+    w = _cls(d)(wname, sizes[0] if d == 1 else sizes, "pres_l2_norm", l2, "precision", precision)
+    y = w.dec(_colmajor_gpu(x, precision), level)
+    assert not y.is_complex()                                                                  # (E) real in -> real out
+    want = orc.spatial_dec(x, wname, level, l2)
+    assert _relerr(y.cpu().numpy(), want) <= TOL[precision]
+    c = rng.standard_normal(list(sizes) + [orc.num_bands(d, level)])
+    r = w.rec(_colmajor_gpu(c, precision))
+    assert _relerr(r.cpu().numpy(), orc.spatial_rec(c, wname, l2)) <= TOL[precision]
+
+
+def test_fused_and_per_axis_kernels_agree_with_uneven_chunks():
+    """same plan, fused vs per-axis path, several workgroup chunkings of the marched axis"""
+    sizes = [100, 52, 37]
+    x = torch.randn(*reversed(sizes), device="cuda", dtype=torch.float64).permute(2, 1, 0)
+    w = ndwt.nd_dwt_3D(["db4", "db2", "db3"], sizes, "pres_l2_norm", 1)
+    ref = None
+    for generic, zc in ((True, 0), (False, 0), (False, 5), (False, 37), (False, 16)):
+        w.dec(x, 1)
+        p = list(w._plans.values())[0]
+        p.set_path(generic)
+        p.set_tuning(0, zc)
+        y = w.dec(x, 3)
+        r = w.rec(y)
+        if ref is None:
+            ref = y
+        assert float((y - ref).abs().max()) < 1e-12
+        assert float((r - x).abs().max()) < 1e-12
+
+
+def test_host_offload_compute_and_numpy_io():
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((33, 20, 18))
+    w = ndwt.nd_dwt_3D("db2", [33, 20, 18], "compute", "hip_off")
+    y = w.dec(x, 2)
+    assert isinstance(y, np.ndarray) and y.shape == (33, 20, 18, 15)
+    assert _relerr(y, orc.spatial_dec(x, "db2", 2, 0)) < 1e-12
+    assert _relerr(w.rec(y), x) < 1e-12
+    # row vectors are transposed like nd_dwt_1D.m:151-153
+    w1 = ndwt.nd_dwt_1D("db3", 50, "compute", "gpu_off")
+    xr = rng.standard_normal((1, 50))
+    assert _relerr(w1.dec(xr, 2), orc.spatial_dec(xr.reshape(-1), "db3", 2, 0)) < 1e-12
+
+
+def test_host_pointer_entry_points_of_the_c_abi():
+    import ctypes
+    api = __import__("importlib").import_module("non-decimated_wavelets_amd.api")
+    p = api.Plan([24, 10, 12], ["db2", "db1", "db3"], torch.float64, max_level=2)
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((24, 10, 12))
+    xk = np.ascontiguousarray(x.T)
+    yk = np.empty((15, 12, 10, 24))
+    ndwt._lib.check(ndwt.lib().ndwt_dec_host(p._h, xk.ctypes.data_as(ctypes.c_void_p), yk.ctypes.data_as(ctypes.c_void_p), 2))
+    assert _relerr(yk.T, orc.spatial_dec(x, ["db2", "db1", "db3"], 2, 0)) < 1e-12
+    xr = np.empty_like(xk)
+    ndwt._lib.check(ndwt.lib().ndwt_rec_host(p._h, yk.ctypes.data_as(ctypes.c_void_p), xr.ctypes.data_as(ctypes.c_void_p), 2))
+    assert _relerr(xr, xk) < 1e-12
+    with pytest.raises(ndwt.NdwtError):
+        p.dec(0, 0, 1)                                     # null pointers are an error, not a crash
+    with pytest.raises(ndwt.NdwtError, match="max_level"):
+        p.dec(1, 1, 5)
+
+
+def test_properties_linearity_shift_adjoint():
+    torch.manual_seed(0)
+    sizes = [48, 36, 40]
+    w = ndwt.nd_dwt_3D("db4", sizes, "pres_l2_norm", 1)
+    mk = lambda: torch.randn(40, 36, 48, device="cuda", dtype=torch.float64).permute(2, 1, 0)
+    a, b = mk(), mk()
+    ya, yb = w.dec(a, 2), w.dec(b, 2)
+    assert float((w.dec(2.5 * a - b, 2) - (2.5 * ya - yb)).abs().max()) < 1e-12              # linearity
+    sh = (5, -3, 7)
+    ys = w.dec(torch.roll(a, sh, dims=(0, 1, 2)), 2)
+    assert float((ys - torch.roll(ya, sh, dims=(0, 1, 2))).abs().max()) < 1e-12              # periodic shift equivariance
+    c = torch.randn(15, 40, 36, 48, device="cuda", dtype=torch.float64).permute(3, 2, 1, 0)
+    lhs = float((ya * c).sum())
+    rhs = float((a * w.rec(c)).sum())
+    assert abs(lhs - rhs) < 1e-9 * max(abs(lhs), 1.0)                                          # <dec x, c> = <x, rec c> in l2 mode
+
+
+@pytest.mark.parametrize("wname,level,sizes", [("db4", 3, [512, 512, 512]), ("db6", 4, [512, 512, 128])],
+                         ids=["cfg3_512cube_db4_L3", "db6_L4_512x512x128"])
+def test_full_size_fp32_roundtrip_and_energy(wname, level, sizes):
+    """BASELINE config 3 at full size: properties only (the oracle cannot run this in seconds)."""
+    torch.manual_seed(1)
+    n1, n2, n3 = sizes
+    x = torch.randn(n3, n2, n1, device="cuda", dtype=torch.float32).permute(2, 1, 0)
+    w = ndwt.nd_dwt_3D(wname, sizes, "pres_l2_norm", 1, "precision", "single")
+    y = w.dec(x, level)
+    assert y.shape[-1] == 8 + 7 * (level - 1)
+    nx = float(torch.linalg.vector_norm(x.double()))
+    ny = float(torch.sqrt(sum(torch.linalg.vector_norm(y[..., b].double()) ** 2 for b in range(y.shape[-1]))))
+    assert abs(ny - nx) < 2e-6 * nx                                                           # energy (B)
+    r = w.rec(y)
+    del y
+    rel = float(torch.linalg.vector_norm((r - x).double())) / nx
+    assert rel < 1e-6, rel                                                                     # round trip (A), relative l2
+    # spot-check one z-column of the finest LLH.. bands against the oracle restricted to a sub-volume is not
+    # possible (periodic), so compare against the per-axis kernels on a smaller crop with the same tiles
+    xs = x[:128, :64, :72].contiguous().permute(2, 1, 0).contiguous().permute(2, 1, 0)
+    ws = ndwt.nd_dwt_3D(wname, [128, 64, 72], "pres_l2_norm", 1, "precision", "single")
+    yf = ws.dec(xs, 2)
+    for p in ws._plans.values():
+        p.set_path(True)
+    yg = ws.dec(xs, 2)
+    assert float((yf - yg).abs().max()) < 2e-6 * float(yg.abs().max())
+
+
+def test_slab_entry_points_reproduce_the_periodic_transform():
+    """two z-slabs with explicit halos == the periodic single-device level (fused and per-axis paths)"""
+    api = __import__("importlib").import_module("non-decimated_wavelets_amd.api")
+    n1, n2, n3 = 40, 24, 32
+    for dtype, tol in ((torch.float64, 1e-12), (torch.float32, 2e-6)):
+        for generic in (False, True):
+            x = torch.randn(n3, n2, n1, device="cuda", dtype=dtype)
+            full = api.Plan([n1, n2, n3], ["db3"] * 3, dtype, max_level=1)
+            full.set_path(generic)
+            y = torch.empty(8, n3, n2, n1, device="cuda", dtype=dtype)
+            full.dec(x.data_ptr(), y.data_ptr(), 1)
+            half = api.Plan([n1, n2, n3 // 2], ["db3"] * 3, dtype, max_level=1)
+            half.set_path(generic)
+            ab, aa, sb, sa = half.slab_halo(1)
+            assert (ab, aa, sb, sa) == (2, 3, 3, 2)
+            r = torch.empty(n3, n2, n1, device="cuda", dtype=dtype)
+            for k in range(2):
+                z0 = k * n3 // 2
+                idx = torch.arange(z0 - ab, z0 + n3 // 2 + aa, device="cuda") % n3
+                xin = x[idx].contiguous()
+                outs = torch.empty(8, n3 // 2, n2, n1, device="cuda", dtype=dtype)
+                half.analysis_level_slab(xin.data_ptr(), [outs[b].data_ptr() for b in range(8)], 1)
+                assert float((outs - y[:, z0:z0 + n3 // 2]).abs().max()) <= tol * float(y.abs().max())
+                idx = torch.arange(z0 - sb, z0 + n3 // 2 + sa, device="cuda") % n3
+                yin = y[:, idx].contiguous()
+                rk = torch.empty(n3 // 2, n2, n1, device="cuda", dtype=dtype)
+                half.synthesis_level_slab([yin[b].data_ptr() for b in range(8)], rk.data_ptr(), 1)
+                r[z0:z0 + n3 // 2] = rk
+            torch.cuda.synchronize()
+            assert float((r - x).abs().max()) <= 10 * tol * float(x.abs().max())
