@@ -182,7 +182,7 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cores = os.cpu_count() or 1
         workers = min(cores, 16)
-        sample = [256, 256, 128] if cores >= 32 else [192, 192, 128]
+        sample = [512, 512, 128] if cores >= 16 else [192, 192, 128]
         v, secs = cpu_baseline(level, a.wname, sample, workers)
         out["cpu_baseline"] = {"value": round(v, 2), "unit": "Mvoxels/s", "cores": workers, "kind": "port",
                                "sample": f"{sample[0]}x{sample[1]}x{sample[2]} fp64/complex128 {a.wname} {level} levels dec+rec, FFT-domain "

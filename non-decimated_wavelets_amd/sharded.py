@@ -1,0 +1,229 @@
+"""Outer-axis slab decomposition of the NDWT across the GPUs of one node (one process per GPU).
+
+The reference is single-process (no MPI/NCCL anywhere); this is the multi-GPU extension named
+by BASELINE.json: 3-D/4-D volumes are sharded on the outermost axis, every band of every level is sharded the same
+way, and each level needs one periodic halo exchange on that axis -- `torch.distributed` point-to-point sends
+(backend "nccl" = RCCL over xGMI on the GPUs; "gloo" in the CPU tests).
+
+Two exchange schemes:
+  * analysis: the (L/2-1)*s planes before and (L/2)*s planes after the slab of the APPROXIMATION band are fetched
+    from their owners (1 band per level).
+  * synthesis, scheme "scatter" (default where the engine supports it): each rank synthesises its own coefficient
+    slab zero-extended, which yields partial sums for the (L/2-1)*s planes before and (L/2)*s planes after its slab;
+    those partial planes (1 band) are sent to their owners and added -- 2^d times less traffic than fetching the
+    halo of all 2^d bands, and no haloed copy of the coefficients.  Summation order differs from the single-device
+    kernel, so results agree to rounding, not bit for bit.
+  * synthesis, scheme "gather": fetch the halo planes of all 2^d bands, then run the slab synthesis.  Bit-exact
+    with the single-device result; used for the per-axis path.
+
+Tensors are in kernel order: x_local is (n_local, n_{d-1}, ..., n1) contiguous, coefficients are
+(bands, n_local, ..., n1) -- i.e. the column-major MATLAB arrays [n1, ..., n_local, bands] of the reference.
+The local compute is delegated to an engine object; the product engine is `HipSlabEngine` (HIP kernels through the
+C ABI).  The CPU tests inject an oracle-backed engine to exercise the exchange logic without a GPU.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+
+
+def partition(n: int, world: int):
+    """plane ranges [lo, hi) of every rank (uneven remainders allowed)"""
+    return [(r * n // world, (r + 1) * n // world) for r in range(world)]
+
+
+class HipSlabEngine:
+    """Local compute of one slab on one GPU through include/ndwt.h (slab entry points)."""
+
+    def __init__(self, wnames, local_dims, dtype, pres_l2_norm, dilation, device):
+        from .api import Plan
+        self.plan = Plan(local_dims, wnames, dtype, False, pres_l2_norm, dilation, max_level=1, device=device.index or 0)
+        self.device = device
+        self.dtype = dtype
+        self.local_dims = list(local_dims)
+        self.supports_scatter = self.plan.describe() == "fused3d"
+
+    def halo(self, stride):
+        return self.plan.slab_halo(stride)
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def analysis(self, in_with_halo, outs, stride):
+        self.plan.analysis_level_slab(in_with_halo.data_ptr(), [o.data_ptr() for o in outs], stride, self._stream())
+
+    def synthesis(self, ins_with_halo, out, stride):
+        self.plan.synthesis_level_slab([t.data_ptr() for t in ins_with_halo], out.data_ptr(), stride, self._stream())
+
+    def analysis_split(self, in_local, halo_before, halo_after, outs, stride):
+        self.plan.analysis_level_slab_split(in_local.data_ptr(), halo_before.data_ptr(), halo_after.data_ptr(),
+                                            [o.data_ptr() for o in outs], stride, self._stream())
+
+    def synthesis_ext(self, ins_local, out_ext, stride):
+        self.plan.synthesis_level_slab_ext([t.data_ptr() for t in ins_local], out_ext.data_ptr(), stride, self._stream())
+
+
+class ShardedNdDwt:
+    def __init__(self, wname, sizes, pres_l2_norm=False, precision="double", dilation="reference", group=None, device=None,
+                 engine=None, synthesis_scheme="auto"):
+        self.sizes = [int(s) for s in sizes]
+        self.d = len(self.sizes)
+        self.wname = [wname] * self.d if isinstance(wname, str) else list(wname)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.n_outer = self.sizes[-1]
+        self.parts = partition(self.n_outer, self.world)
+        self.z0, self.z1 = self.parts[self.rank]
+        self.n_local = self.z1 - self.z0
+        if min(hi - lo for lo, hi in self.parts) < 1:
+            raise ValueError("every rank needs at least one plane of the outer axis")
+        self.dtype = torch.float32 if precision == "single" else torch.float64
+        self.dilation = dilation
+        self.device = device if device is not None else torch.device("cpu")
+        self.inner_shape = tuple(reversed(self.sizes[:-1]))          # kernel order of the unsharded axes
+        local_dims = self.sizes[:-1] + [self.n_local]
+        self.engine = engine if engine is not None else HipSlabEngine(self.wname, local_dims, self.dtype, pres_l2_norm,
+                                                                     dilation, self.device)
+        self.plan = getattr(self.engine, "plan", None)
+        if synthesis_scheme == "auto":
+            synthesis_scheme = "scatter" if getattr(self.engine, "supports_scatter", False) else "gather"
+        self.scheme = synthesis_scheme
+        self.nb = 1 << self.d
+
+    # ---------------------------------------------------------------------------------- plumbing
+    def _owner(self, g):
+        for r, (lo, hi) in enumerate(self.parts):
+            if lo <= g < hi:
+                return r
+        raise AssertionError(g)
+
+    def _plan_exchange(self, before, after):
+        """who needs which global planes: list of (dst, side, src, [global planes]) in a rank-independent order"""
+        msgs = []
+        for q, (lo, hi) in enumerate(self.parts):
+            for side, planes in ((0, range(lo - before, lo)), (1, range(hi, hi + after))):
+                by_src = {}
+                for k, g in enumerate(planes):
+                    gm = g % self.n_outer
+                    by_src.setdefault(self._owner(gm), []).append((k, gm))
+                for p in sorted(by_src):
+                    msgs.append((q, side, p, by_src[p]))
+        return msgs
+
+    def _run_p2p(self, ops):
+        if not ops:
+            return
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+    def _fetch_halo(self, t, ax, before, after):
+        """t: local tensor whose dim `ax` is the sharded axis.  Returns (halo_before, halo_after) tensors."""
+        shp = list(t.shape)
+        hb = t.new_empty(shp[:ax] + [before] + shp[ax + 1:])
+        ha = t.new_empty(shp[:ax] + [after] + shp[ax + 1:])
+        ops, keep, post = [], [], []
+        for q, side, p, items in self._plan_exchange(before, after):
+            ks = [k for k, _ in items]
+            ls = [g - self.parts[p][0] for _, g in items]
+            if p == self.rank and q == self.rank:                       # own planes (periodic wrap inside the slab)
+                dst = hb if side == 0 else ha
+                dst.index_copy_(ax, torch.tensor(ks, device=t.device), t.index_select(ax, torch.tensor(ls, device=t.device)))
+            elif p == self.rank:
+                buf = t.index_select(ax, torch.tensor(ls, device=t.device)).contiguous()
+                keep.append(buf)
+                ops.append(dist.P2POp(dist.isend, buf, self._global_rank(q), self.group))
+            elif q == self.rank:
+                buf = t.new_empty(shp[:ax] + [len(ks)] + shp[ax + 1:])
+                ops.append(dist.P2POp(dist.irecv, buf, self._global_rank(p), self.group))
+                post.append((hb if side == 0 else ha, ks, buf))
+        self._run_p2p(ops)
+        for dst, ks, buf in post:
+            dst.index_copy_(ax, torch.tensor(ks, device=t.device), buf)
+        return hb, ha
+
+    def _scatter_add(self, ext, before, after):
+        """ext: (before + n_local + after, ...) partial sums; planes outside the slab go to their owners and are added.
+        Returns the completed local slab (a view of ext)."""
+        ops, keep, post = [], [], []
+        own = ext.narrow(0, before, self.n_local)
+        local_adds = []
+        # rank q PRODUCES partial planes for the global planes around its slab; the owner p ADDS them
+        for q, side, p, items in self._plan_exchange(before, after):
+            ks = [k for k, _ in items]
+            ls = [g - self.parts[p][0] for _, g in items]
+            if q == self.rank:
+                src_idx = [k if side == 0 else before + self.n_local + k for k in ks]
+                part = ext.index_select(0, torch.tensor(src_idx, device=ext.device)).contiguous()
+                if p == self.rank:
+                    local_adds.append((ls, part))
+                else:
+                    keep.append(part)
+                    ops.append(dist.P2POp(dist.isend, part, self._global_rank(p), self.group))
+            elif p == self.rank:
+                buf = ext.new_empty([len(ks)] + list(ext.shape[1:]))
+                ops.append(dist.P2POp(dist.irecv, buf, self._global_rank(q), self.group))
+                post.append((ls, buf))
+        self._run_p2p(ops)
+        for ls, buf in local_adds + post:
+            own.index_add_(0, torch.tensor(ls, device=ext.device), buf)
+        return own
+
+    def _global_rank(self, r):
+        return r if self.group is None or self.group is dist.group.WORLD else dist.get_global_rank(self.group, r)
+
+    def _stride(self, lev):
+        return 1 if self.dilation == "reference" else 1 << (lev - 1)
+
+    # --------------------------------------------------------------------------------- transform
+    def dec(self, x_local, level):
+        """x_local: (n_local, ..., n1) -> (bands, n_local, ..., n1); band order of the reference (nddwt.c:210)."""
+        nb, nbt = self.nb, self.nb + (self.nb - 1) * (level - 1)
+        x_local = x_local.to(self.dtype).contiguous()
+        y = x_local.new_empty((nbt,) + tuple(x_local.shape))
+        cur = x_local
+        spare = [None, None]
+        for lev in range(1, level + 1):
+            s = self._stride(lev)
+            ab, aa, _, _ = self.engine.halo(s)
+            if lev == level:
+                a_out = y[0]
+            else:
+                if spare[(lev - 1) & 1] is None:
+                    spare[(lev - 1) & 1] = torch.empty_like(x_local)
+                a_out = spare[(lev - 1) & 1]
+            outs = [a_out] + [y[1 + (nb - 1) * (level - lev) + (b - 1)] for b in range(1, nb)]
+            hb, ha = self._fetch_halo(cur, 0, ab, aa)
+            if hasattr(self.engine, "analysis_split") and getattr(self.engine, "supports_scatter", False):
+                self.engine.analysis_split(cur, hb, ha, outs, s)
+            else:
+                self.engine.analysis(torch.cat([hb, cur, ha], 0), outs, s)
+            cur = a_out
+        return y
+
+    def rec(self, y):
+        """(bands, n_local, ..., n1) -> (n_local, ..., n1)"""
+        nb = self.nb
+        level = 1 + (y.shape[0] - nb) // (nb - 1)
+        y = y.to(self.dtype).contiguous()
+        prev = y[0]
+        for ind in range(1, level + 1):
+            lev = level - ind + 1
+            s = self._stride(lev)
+            _, _, sb, sa = self.engine.halo(s)
+            ins = [prev] + [y[1 + (nb - 1) * (level - lev) + (b - 1)] for b in range(1, nb)]
+            if self.scheme == "scatter":
+                # zero-extended synthesis: partial sums for sa planes before and sb planes after the slab
+                ext = prev.new_empty((sa + self.n_local + sb,) + tuple(prev.shape[1:]))
+                self.engine.synthesis_ext(ins, ext, s)
+                prev = self._scatter_add(ext, sa, sb)
+            else:
+                stack = torch.stack(ins, 0)
+                hb, ha = self._fetch_halo(stack, 1, sb, sa)
+                full = torch.cat([hb, stack, ha], 1)
+                out = torch.empty_like(prev)
+                self.engine.synthesis([full[b] for b in range(nb)], out, s)
+                prev = out
+        return prev.contiguous()
