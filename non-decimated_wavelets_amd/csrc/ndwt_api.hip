@@ -76,6 +76,8 @@ struct ndwt_plan {
     size_t tmp_bytes;
     int target_blocks;                 // fused-kernel grid sizing
     int force_zchunk;
+    int variant_fwd, variant_inv;      // fused-kernel variants (tuning experiments; same results)
+    void* taps_dev[2];                 // device tap tables of the fused kernels: [0] analysis, [1] synthesis (Taps3<T, Lp>)
     // optional per-kernel timing with HIP events on the launch stream (bench.py's roofline figures)
     int profiling;
     std::vector<ProfRec>* prof;
@@ -211,13 +213,22 @@ static FusedTapsD fused_taps(const ndwt_plan* p, int Lp, bool synthesis) {
 
 template <typename T> static bool aligned_vec4(const void* ptr) { return ((uintptr_t)ptr % (4 * sizeof(T))) == 0; }
 
-template <typename T> static int launch3(bool inverse, const Fused3Args<T>& a, const FusedTapsD& t, bool vec4, hipStream_t s);
-template <> int launch3<float>(bool inverse, const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, hipStream_t s) {
-    return inverse ? launch_inv3_f32(a, t, vec4, s) : launch_fwd3_f32(a, t, vec4, s);
+template <typename T> static int launch3(bool inverse, const Fused3Args<T>& a, const FusedTapsD& t, bool vec4, int variant, const void* td, hipStream_t s);
+template <> int launch3<float>(bool inverse, const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, int variant, const void* td, hipStream_t s) {
+    return inverse ? launch_inv3_f32(a, t, vec4, variant, td, s) : launch_fwd3_f32(a, t, vec4, variant, td, s);
 }
-template <> int launch3<double>(bool inverse, const Fused3Args<double>& a, const FusedTapsD& t, bool vec4, hipStream_t s) {
-    return inverse ? launch_inv3_f64(a, t, vec4, s) : launch_fwd3_f64(a, t, vec4, s);
+template <> int launch3<double>(bool inverse, const Fused3Args<double>& a, const FusedTapsD& t, bool vec4, int variant, const void* td, hipStream_t s) {
+    return inverse ? launch_inv3_f64(a, t, vec4, variant, td, s) : launch_fwd3_f64(a, t, vec4, variant, td, s);
 }
+
+namespace ndwt {
+void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int* TY) {
+    (void)Lp;
+    *TX = 64;
+    *TY = f64 ? 8 : 16;
+    if (!f64 && inverse && variant == 1 && Lp == 8) *TY = Fused3Tile<float, true, 1>::TY;
+}
+}  // namespace ndwt
 
 // one fused 3-D launch over `nbatch` volumes. n3 = output planes; z_wrap=false: inputs carry the z halo
 template <typename T>
@@ -232,14 +243,20 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     a.in_bstride = in_bstride;
     a.out_bstride = out_bstride;
     a.z_wrap = z_wrap ? 1 : 0;
+    if (const char* v = getenv("NDWT_DEBUG")) a.dbg = atoi(v);   // timing experiments only
     bool vec4 = (a.n1 % 4 == 0) && (in_bstride % 4 == 0) && (out_bstride % 4 == 0);
     const int nin = inverse ? 8 : 1, nout = inverse ? 1 : 8;
     for (int b = 0; b < nin; ++b) { a.in[b] = in[b]; vec4 = vec4 && aligned_vec4<T>(in[b]); }
     for (int b = 0; b < nout; ++b) { a.out[b] = out[b]; vec4 = vec4 && aligned_vec4<T>(out[b]); }
-    fused3_geometry(a, Fused3Tile<T>::TX, Fused3Tile<T>::TY, Lp, p->target_blocks, p->force_zchunk);
+    int TX = 0, TY = 0;
+    const int variant = inverse ? p->variant_inv : p->variant_fwd;
+    fused3_tile_shape(sizeof(T) == 8, inverse, variant, Lp, &TX, &TY);
+    fused3_geometry(a, TX, TY, Lp, p->target_blocks, p->force_zchunk);
     FusedTapsD t = fused_taps(p, Lp, inverse);
+    const void* td = p->taps_dev[inverse ? 1 : 0];
+    if (!td) return fail(NDWT_ERR_UNSUPPORTED, "plan has no device tap table");
     prof_begin(p, inverse ? NDWT_KERNEL_FUSED_SYNTHESIS : NDWT_KERNEL_FUSED_ANALYSIS, s);
-    int rc = launch3<T>(inverse, a, t, vec4, s);
+    int rc = launch3<T>(inverse, a, t, vec4, variant, td, s);
     prof_end(p, s);
     if (rc == -1) return fail(NDWT_ERR_UNSUPPORTED, "no fused kernel instantiated for tap length %d", Lp);
     if (rc != 0) return fail(NDWT_ERR_HIP, "fused kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -436,6 +453,8 @@ int ndwt_plan_create(ndwt_plan** plan, int ndim, const int64_t* dims, const char
     p->comp = complexity == NDWT_COMPLEX_INTERLEAVED ? 2 : 1;
     p->target_blocks = 2048;
     p->prof = new std::vector<ProfRec>();
+    if (const char* v = getenv("NDWT_VARIANT_FWD")) p->variant_fwd = atoi(v);
+    if (const char* v = getenv("NDWT_VARIANT_INV")) p->variant_inv = atoi(v);
     static const char* ordn[4] = {"First", "Second", "Third", "Fourth"};
     p->vol = p->comp;
     for (int a = 0; a < ndim; ++a) {
@@ -467,6 +486,29 @@ int ndwt_plan_create(ndwt_plan** plan, int ndim, const int64_t* dims, const char
             return fail(NDWT_ERR_ALLOC, "hipMalloc of the approximation scratch failed: %s", hipGetErrorString(e));
         }
     }
+    int Lp = 0;
+    if (fused3_eligible(p, 1, &Lp)) {
+        for (int inv = 0; inv < 2; ++inv) {
+            FusedTapsD t = fused_taps(p, Lp, inv != 0);
+            std::vector<char> host((size_t)6 * Lp * p->esize);
+            for (int ax = 0; ax < 3; ++ax)
+                for (int j = 0; j < Lp; ++j) {
+                    if (dtype == NDWT_F32) {
+                        ((float*)host.data())[ax * Lp + j] = (float)t.lo[ax][j];
+                        ((float*)host.data())[3 * Lp + ax * Lp + j] = (float)t.hi[ax][j];
+                    } else {
+                        ((double*)host.data())[ax * Lp + j] = t.lo[ax][j];
+                        ((double*)host.data())[3 * Lp + ax * Lp + j] = t.hi[ax][j];
+                    }
+                }
+            hipError_t e = hipMalloc(&p->taps_dev[inv], host.size());
+            if (e == hipSuccess) e = hipMemcpy(p->taps_dev[inv], host.data(), host.size(), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                ndwt_plan_destroy(p);
+                return fail(NDWT_ERR_ALLOC, "uploading the tap table failed: %s", hipGetErrorString(e));
+            }
+        }
+    }
     *plan = p;
     return NDWT_OK;
 }
@@ -477,6 +519,8 @@ int ndwt_plan_destroy(ndwt_plan* p) {
     for (int i = 0; i < 2; ++i)
         if (p->approx[i]) (void)hipFree(p->approx[i]);
     if (p->tmp) (void)hipFree(p->tmp);
+    for (int i = 0; i < 2; ++i)
+        if (p->taps_dev[i]) (void)hipFree(p->taps_dev[i]);
     if (p->prof) {
         for (auto& r : *p->prof) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
         delete p->prof;

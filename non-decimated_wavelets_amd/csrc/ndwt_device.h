@@ -57,7 +57,7 @@ template <int I, int N, class F> NDWT_DEV void static_for(F&& f) {
         static_for<I + 1, N>(f);
     }
 }
-#define NDWT_SFOR(var, N) static_for<0, N>([&](auto var##_c) { constexpr int var = decltype(var##_c)::value;
+#define NDWT_SFOR(var, N) static_for<0, N>([&](auto var##_c) __attribute__((always_inline)) { constexpr int var = decltype(var##_c)::value;
 #define NDWT_SEND });
 
 // ------------------------------------------------------------------------------------------------
@@ -142,6 +142,7 @@ template <typename T> struct Fused3Args {
     int zchunk;            // output planes per workgroup
     int ntx, nty, nzc;     // tiles per axis
     int z_wrap;            // 1: periodic in z; 0: inputs start `left` planes before local plane 0 (slab mode)
+    int dbg;               // timing experiments only (wrong results): bit0 = fold halo reads back into the tile
 };
 
 // XCD-aware block order: hardware deals workgroups round-robin over the 8 XCDs (each with its own
@@ -176,33 +177,100 @@ template <typename T> NDWT_DEV TileCoord decode_tile(const Fused3Args<T>& a, int
     return tc;
 }
 
+// ------------------------------------------------------------------------------------ LDS rows ----
+// LDS tiles are rows of 16-byte chunks (float: 2 (lo,hi) pairs per chunk; double: 1 pair).  Every access is a
+// whole chunk (ds_read_b128 / ds_write_b128: 256 B/clk, twice the rate of the ds_read2_b64 hipcc emits for 8-byte
+// aligned pairs).  Chunk c of a row is stored at position S(c): lanes that each own 4 consecutive pairs step
+// through chunks 2g+k (float) / 4g+k (double), i.e. every 2nd / 4th chunk, which without the swizzle puts lanes
+// g and g+8 (g+4) on the same banks.  S permutes chunks inside aligned groups of 2 (float) / 4 (double), so
+// rows must hold a multiple of 2 / 4 chunks.  Checked with tools/lds_bank_sim.py.
+template <typename T> struct Lds;
+template <> struct Lds<float> {
+    typedef VecT<float>::v2 v2;
+    typedef VecT<float>::v4 chunk;
+    static constexpr int CH = 2;                                           // pairs per chunk
+    static NDWT_DEV int S(int c) { return c ^ (((c >> 3) ^ (c >> 4)) & 1); }
+    static NDWT_DEV v2 get(const chunk& c, int sub) { return sub ? v2{c[2], c[3]} : v2{c[0], c[1]}; }
+    static NDWT_DEV void set(chunk& c, int sub, v2 v) {
+        if (sub) { c[2] = v[0]; c[3] = v[1]; } else { c[0] = v[0]; c[1] = v[1]; }
+    }
+};
+template <> struct Lds<double> {
+    typedef VecT<double>::v2 v2;
+    typedef VecT<double>::v2 chunk;
+    static constexpr int CH = 1;
+    static NDWT_DEV int S(int c) { return c ^ ((c >> 4) & 3); }
+    static NDWT_DEV v2 get(const chunk& c, int) { return c; }
+    static NDWT_DEV void set(chunk& c, int, v2 v) { c = v; }
+};
+
+// N consecutive pairs starting at pair index u0 (a multiple of 4) of a swizzled row
+template <typename T, int N> NDWT_DEV void lds_load_run(const typename Lds<T>::chunk* row, int u0, typename Lds<T>::v2 (&v)[N]) {
+    typedef Lds<T> LD;
+    static_assert(N % LD::CH == 0, "whole chunks");
+    const int c0 = u0 / LD::CH;
+    NDWT_UNROLL
+    for (int k = 0; k < N / LD::CH; ++k) {
+        typename LD::chunk ch = row[LD::S(c0 + k)];
+        NDWT_UNROLL
+        for (int sub = 0; sub < LD::CH; ++sub) v[k * LD::CH + sub] = LD::get(ch, sub);
+    }
+}
+template <typename T, int N> NDWT_DEV void lds_store_run(typename Lds<T>::chunk* row, int u0, const typename Lds<T>::v2 (&v)[N]) {
+    typedef Lds<T> LD;
+    static_assert(N % LD::CH == 0, "whole chunks");
+    const int c0 = u0 / LD::CH;
+    NDWT_UNROLL
+    for (int k = 0; k < N / LD::CH; ++k) {
+        typename LD::chunk ch;
+        NDWT_UNROLL
+        for (int sub = 0; sub < LD::CH; ++sub) LD::set(ch, sub, v[k * LD::CH + sub]);
+        row[LD::S(c0 + k)] = ch;
+    }
+}
+
+// rows r and r+m of a tile with row stride RSB bytes start on the same bank when m*RSB is a multiple of 256 B.
+// Items that put 16 lanes on each row (a 64-wide tile = 16 groups of 4 x) pair such rows inside one 32-lane
+// half-wave so a ds_read_b128's 16-lane groups, which mix both rows, stay conflict free: slot s -> row.
+template <int RSB> struct RowPair {
+    static constexpr int gcd256 = (RSB % 256 == 0) ? 256 : (RSB % 128 == 0) ? 128 : (RSB % 64 == 0) ? 64 : (RSB % 32 == 0) ? 32 : 16;
+    static constexpr int M = 256 / gcd256;               // 1, 2, 4, 8 or 16
+    static NDWT_DEV int row(int s) { return (s / (2 * M)) * (2 * M) + (s % (2 * M)) / 2 + M * (s % 2); }
+    static constexpr int slots(int nrows) { return ((nrows + 2 * M - 1) / (2 * M)) * (2 * M); }
+};
+
 // ---------------------------------------------------------------------------------- analysis ----
-template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_> struct Fwd3 {
+template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, int WPE_ = 2> struct Fwd3 {
     static constexpr int L = L_, TX = TX_, TY = TY_, NT = NT_, RY = RY_;
     static constexpr bool VEC4 = VEC4_;
     static constexpr int NE = VEC4 ? 1 : 4;              // offsets kept per column
+    static constexpr int WPE = WPE_;                     // waves per SIMD the register budget is sized for
     static constexpr int LH = L / 2 - 1;                 // samples left of the output index
     static constexpr int RH = L / 2;                     // samples right of it
     static constexpr int GL = (LH + 3) / 4, GR = (RH + 3) / 4;   // halo in groups of 4 x
-    static constexpr int W = TX + 4 * (GL + GR);         // haloed tile width
+    static constexpr int W = TX + 4 * (GL + GR);         // haloed tile width (pairs per LDS row)
     static constexpr int NG = W / 4;
     static constexpr int NR = TY + L - 1;                // haloed tile rows
     static constexpr int NCOLS = NG * NR;                // z-stage columns (4 x each)
     static constexpr int NCOL = (NCOLS + NT - 1) / NT;   // columns per thread
-    static constexpr int YITEMS = W * (TY / RY);
+    typedef Lds<T> LD;
+    static constexpr int CH = LD::CH;
+    static constexpr int WC = W / CH;                    // chunks per LDS row
+    static constexpr int YITEMS = WC * (TY / RY);        // y-stage item: one chunk column, RY output rows
     static constexpr int NYI = (YITEMS + NT - 1) / NT;
-    static constexpr int XITEMS = (TX / 4) * TY * 2;
+    static constexpr int XITEMS = (TX / 4) * TY * 2;     // x-stage item: 4 x of one row of one y-bit plane
     static constexpr int NXI = (XITEMS + NT - 1) / NT;
-    static constexpr int XV = 4 * (1 + GL + GR);         // values an x item reads
-    static_assert(TX % 4 == 0 && TY % RY == 0 && L % 2 == 0, "tile shape");
+    static constexpr int XV = 4 * (1 + GL + GR);         // pairs an x item reads
+    static_assert(TX % 4 == 0 && TY % RY == 0 && L % 2 == 0 && W % 4 == 0, "tile shape");
     typedef typename VecT<T>::v2 v2;
     typedef typename VecT<T>::v4 v4;
+    typedef typename LD::chunk chunk;
     typedef Taps3<T, L> Taps;
     typedef Fused3Args<T> Args;
 
     struct Shared {
-        v2 zs[NR][W];        // (lo3, hi3) of the raw tile
-        v2 ys[2][TY][W];     // [y-bit][row][x] of (z-bit 0, z-bit 1)
+        chunk zs[NR][WC];        // (lo3, hi3) of the raw tile
+        chunk ys[TY][2][WC];     // [row][y-bit][x] of (z-bit 0, z-bit 1); y-bit planes of a row are a multiple of 256 B apart
     };
     struct State {
         v4 win[NCOL][L];     // raw samples of the last L planes, rotating
@@ -217,6 +285,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_> st
             int ug = c % NG, r = c / NG;
             int y = modn(tc.y0 - LH + r, a.n2);
             int xb = tc.x0 - 4 * GL + 4 * ug;
+            if (a.dbg & 1) { y = modn(tc.y0 + r % TY, a.n2); xb = tc.x0 + 4 * (ug % (TX / 4)); }
             NDWT_SFOR(e, NE)
                 st.off[k][e] = y * a.n1 + modn(xb + e, a.n1);
             NDWT_SEND
@@ -243,15 +312,15 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_> st
             st.win[k][(R + L - 1) % L] = st.nxt[k];
             int c = tid + k * NT;
             if (c < NCOLS) {
-                v2 a0 = (v2)(T(0)), a1 = (v2)(T(0)), a2 = (v2)(T(0)), a3 = (v2)(T(0));
+                v2 acc[4];
+                acc[0] = acc[1] = acc[2] = acc[3] = (v2)(T(0));
                 NDWT_SFOR(j, L)
                     v4 w = st.win[k][(R + j) % L];
                     v2 t = {tp.lo[2][j], tp.hi[2][j]};
-                    a0 += t * w[0]; a1 += t * w[1]; a2 += t * w[2]; a3 += t * w[3];
+                    acc[0] += t * w[0]; acc[1] += t * w[1]; acc[2] += t * w[2]; acc[3] += t * w[3];
                 NDWT_SEND
                 int ug = c % NG, r = c / NG;
-                v2* dst = &sh.zs[r][4 * ug];
-                dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3;
+                lds_store_run<T, 4>(sh.zs[r], 4 * ug, acc);
             }
         NDWT_SEND
     }
@@ -270,29 +339,40 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_> st
         NDWT_SEND
     }
 
+    // y filter: an item owns one chunk column (CH adjacent x) and RY output rows
     static NDWT_DEV void ystage(Shared& sh, const Taps& tp, int tid) {
         NDWT_UNROLL
         for (int k = 0; k < NYI; ++k) {
             int it = tid + k * NT;
             if (it >= YITEMS) continue;
-            int u = it % W, yg = it / W;
-            v2 zin[RY + L - 1];
+            int cc = it % WC, yg = it / WC;
+            const int pc = LD::S(cc);
+            chunk zin[RY + L - 1];
             NDWT_UNROLL
-            for (int r = 0; r < RY + L - 1; ++r) zin[r] = sh.zs[yg * RY + r][u];
+            for (int r = 0; r < RY + L - 1; ++r) zin[r] = sh.zs[yg * RY + r][pc];
             NDWT_UNROLL
             for (int i = 0; i < RY; ++i) {
-                v2 lo = (v2)(T(0)), hi = (v2)(T(0));
+                chunk lo, hi;
                 NDWT_UNROLL
-                for (int j = 0; j < L; ++j) {
-                    lo += tp.lo[1][j] * zin[i + j];
-                    hi += tp.hi[1][j] * zin[i + j];
+                for (int sub = 0; sub < CH; ++sub) {
+                    v2 l = (v2)(T(0)), h = (v2)(T(0));
+                    NDWT_UNROLL
+                    for (int j = 0; j < L; ++j) {
+                        v2 z = LD::get(zin[i + j], sub);
+                        l += tp.lo[1][j] * z;
+                        h += tp.hi[1][j] * z;
+                    }
+                    LD::set(lo, sub, l);
+                    LD::set(hi, sub, h);
                 }
-                sh.ys[0][yg * RY + i][u] = lo;
-                sh.ys[1][yg * RY + i][u] = hi;
+                sh.ys[yg * RY + i][0][pc] = lo;
+                sh.ys[yg * RY + i][1][pc] = hi;
             }
         }
     }
 
+    // x filter + stores: item order (4-x group fastest, then y-bit, then row): the two 16-lane halves of a
+    // 32-lane group read the two y-bit planes of one row
     static NDWT_DEV void xstage(Shared& sh, const Taps& tp, const Args& a, const TileCoord& tc, long long obase, int z,
                                 int tid) {
         NDWT_UNROLL
@@ -300,13 +380,12 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_> st
             int it = tid + k * NT;
             if (it >= XITEMS) continue;
             int xg = it % (TX / 4);
-            int y = (it / (TX / 4)) % TY;
-            int q = it / ((TX / 4) * TY);
+            int q = (it / (TX / 4)) % 2;
+            int y = it / ((TX / 4) * 2);
             int gy = tc.y0 + y, gx = tc.x0 + 4 * xg;
-            if (gy >= a.n2 || gx >= a.n1) continue;
             v2 v[XV];
-            NDWT_UNROLL
-            for (int t = 0; t < XV; ++t) v[t] = sh.ys[q][y][4 * xg + t];
+            lds_load_run<T, XV>(sh.ys[y][q], 4 * xg, v);
+            if (gy >= a.n2 || gx >= a.n1) continue;
             v4 o00, o01, o10, o11;                        // [x-bit][z-bit]
             NDWT_UNROLL
             for (int e = 0; e < 4; ++e) {
@@ -342,7 +421,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_> st
         const T* inb = a.in[0] + (long long)tc.batch * a.in_bstride;
         const long long obase = (long long)tc.batch * a.out_bstride;
         // planes zbeg-LH .. zbeg-LH+L-2 into slots 0..L-2, then prefetch the plane of step 0
-        ex.each([&](int tid, State& st) {
+        ex.each([&](int tid, State& st) __attribute__((always_inline)) {
             setup(st, a, tc, tid);
             prologue(st, a, inb, tc.zbeg);
             load_plane(st, a, inb, tc.zbeg + RH);
@@ -350,14 +429,14 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_> st
         const int nsteps = tc.zend - tc.zbeg;
         for (int s = 0; s < nsteps; ++s) {
             const int z = tc.zbeg + s;
-            ex.each([&](int tid, State& st) {
+            ex.each([&](int tid, State& st) __attribute__((always_inline)) {
                 zdispatch<0>(s % L, st, sh, tp, tid);                     // consumes st.nxt
                 if (s + 1 < nsteps) load_plane(st, a, inb, z + 1 + RH);   // prefetch for the next step
             });
             ex.barrier();
-            ex.each([&](int tid, State&) { ystage(sh, tp, tid); });
+            ex.each([&](int tid, State&) __attribute__((always_inline)) { ystage(sh, tp, tid); });
             ex.barrier();
-            ex.each([&](int tid, State&) { xstage(sh, tp, a, tc, obase, z, tid); });
+            ex.each([&](int tid, State&) __attribute__((always_inline)) { xstage(sh, tp, a, tc, obase, z, tid); });
         }
     }
 };
@@ -366,35 +445,42 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_> st
 // x-synthesis and y-synthesis go through LDS on the haloed tile (the 2^3 bands are read with an
 // x/y halo, mostly from L2), the z-synthesis window (L planes of (a,d) pairs) stays in registers.
 // Per new plane: for y-bit 0,1 { raw 4 bands -> LDS; x-synth -> xs[y-bit] } ; y-synth -> P ; z-synth.
-template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_> struct Inv3 {
+template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, int WPE_ = 2> struct Inv3 {
     static constexpr int L = L_, TX = TX_, TY = TY_, NT = NT_, RY = RY_;
     static constexpr bool VEC4 = VEC4_;
     static constexpr int NE = VEC4 ? 1 : 4;
+    static constexpr int WPE = WPE_;                     // waves per SIMD the register budget is sized for
     static constexpr int LH = L / 2;                     // synthesis: samples left of the output index
     static constexpr int RH = L / 2 - 1;                 // samples right of it
     static constexpr int GL = (LH + 3) / 4, GR = (RH + 3) / 4;
     static constexpr int W = TX + 4 * (GL + GR);
     static constexpr int NG = W / 4;
     static constexpr int NR = TY + L - 1;
+    typedef Lds<T> LD;
+    static constexpr int CH = LD::CH;
+    static constexpr int WC = W / CH, TXC = TX / CH;     // chunks per row of the raw / x-synthesised tiles
+    typedef RowPair<WC * 16> RP;                         // row pairing of the x-synthesis items
     static constexpr int LITEMS = 2 * NG * NR;           // load items: (x-bit, row, group of 4 x)
     static constexpr int NLI = (LITEMS + NT - 1) / NT;
-    static constexpr int XITEMS = (TX / 4) * NR;         // x-synthesis items per y-bit
+    static constexpr int XITEMS = (TX / 4) * RP::slots(NR);   // x-synthesis items per y-bit: 4 x of one row
     static constexpr int NXI = (XITEMS + NT - 1) / NT;
-    static constexpr int YITEMS = TX * (TY / RY);        // y/z-synthesis items: one x, RY rows
+    static constexpr int YITEMS = TXC * (TY / RY);       // y/z-synthesis item: one chunk column (CH x), RY rows
     static constexpr int NYI = (YITEMS + NT - 1) / NT;
+    static constexpr int NP = CH * RY;                   // output positions (window columns) per item
     static constexpr int XV = 4 * (1 + GL + GR);
-    static_assert(TX % 4 == 0 && TY % RY == 0 && L % 2 == 0, "tile shape");
+    static_assert(TX % 4 == 0 && TY % RY == 0 && L % 2 == 0 && W % 4 == 0, "tile shape");
     typedef typename VecT<T>::v2 v2;
     typedef typename VecT<T>::v4 v4;
+    typedef typename LD::chunk chunk;
     typedef Taps3<T, L> Taps;
     typedef Fused3Args<T> Args;
 
     struct Shared {
-        v2 raw[2][NR][W];    // [x-bit][row][x] of (z-bit 0, z-bit 1), one y-bit at a time
-        v2 xs[2][NR][TX];    // [y-bit][row][x] after x-synthesis
+        chunk raw[2][NR][WC];    // [x-bit][row][x] of (z-bit 0, z-bit 1), one y-bit at a time
+        chunk xs[2][NR][TXC];    // [y-bit][row][x] after x-synthesis
     };
     struct State {
-        v2 win[NYI][RY][L];  // (a,d) pairs for the z-synthesis, rotating
+        v2 win[NYI][NP][L];  // (a,d) pairs for the z-synthesis, rotating
         v4 pre[NLI][2];      // prefetched raw values: [item][z-bit]
         int off[NLI][NE];
     };
@@ -406,6 +492,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_> st
             int ug = it % NG, r = (it / NG) % NR;
             int y = modn(tc.y0 - LH + r, a.n2);
             int xb = tc.x0 - 4 * GL + 4 * ug;
+            if (a.dbg & 1) { y = modn(tc.y0 + r % TY, a.n2); xb = tc.x0 + 4 * (ug % (TX / 4)); }
             NDWT_SFOR(e, NE)
                 st.off[k][e] = y * a.n1 + modn(xb + e, a.n1);
             NDWT_SEND
@@ -439,12 +526,9 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_> st
             int it = tid + k * NT;
             if (it < LITEMS) {
                 int ug = it % NG, r = (it / NG) % NR, xb = it / (NG * NR);
-                v2* dst = &sh.raw[xb][r][4 * ug];
                 v4 p0 = st.pre[k][0], p1 = st.pre[k][1];
-                dst[0] = v2{p0[0], p1[0]};
-                dst[1] = v2{p0[1], p1[1]};
-                dst[2] = v2{p0[2], p1[2]};
-                dst[3] = v2{p0[3], p1[3]};
+                v2 pr[4] = {v2{p0[0], p1[0]}, v2{p0[1], p1[1]}, v2{p0[2], p1[2]}, v2{p0[3], p1[3]}};
+                lds_store_run<T, 4>(sh.raw[xb][r], 4 * ug, pr);
             }
         NDWT_SEND
     }
@@ -454,23 +538,22 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_> st
         for (int k = 0; k < NXI; ++k) {
             int it = tid + k * NT;
             if (it >= XITEMS) continue;
-            int xg = it % (TX / 4), r = it / (TX / 4);
+            int xg = it % (TX / 4), r = RP::row(it / (TX / 4));
+            if (r >= NR) continue;
             v2 av[XV], dv[XV];
-            NDWT_UNROLL
-            for (int t = 0; t < XV; ++t) {
-                av[t] = sh.raw[0][r][4 * xg + t];
-                dv[t] = sh.raw[1][r][4 * xg + t];
-            }
+            lds_load_run<T, XV>(sh.raw[0][r], 4 * xg, av);
+            lds_load_run<T, XV>(sh.raw[1][r], 4 * xg, dv);
+            v2 acc[4];
             NDWT_UNROLL
             for (int e = 0; e < 4; ++e) {
-                v2 acc = (v2)(T(0));
+                acc[e] = (v2)(T(0));
                 NDWT_UNROLL
                 for (int j = 0; j < L; ++j) {
-                    acc += tp.lo[0][j] * av[4 * GL + e - LH + j];
-                    acc += tp.hi[0][j] * dv[4 * GL + e - LH + j];
+                    acc[e] += tp.lo[0][j] * av[4 * GL + e - LH + j];
+                    acc[e] += tp.hi[0][j] * dv[4 * GL + e - LH + j];
                 }
-                sh.xs[yb][r][4 * xg + e] = acc;
             }
+            lds_store_run<T, 4>(sh.xs[yb][r], 4 * xg, acc);
         }
     }
 
@@ -481,33 +564,48 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_> st
         NDWT_SFOR(k, NYI)
             int it = tid + k * NT;
             if (it < YITEMS) {
-                int x = it % TX, yg = it / TX;
-                v2 av[RY + L - 1], dv[RY + L - 1];
+                int cx = it % TXC, yg = it / TXC;
+                const int pc = LD::S(cx);
+                chunk av[RY + L - 1], dv[RY + L - 1];
                 NDWT_UNROLL
                 for (int t = 0; t < RY + L - 1; ++t) {
-                    av[t] = sh.xs[0][yg * RY + t][x];
-                    dv[t] = sh.xs[1][yg * RY + t][x];
+                    av[t] = sh.xs[0][yg * RY + t][pc];
+                    dv[t] = sh.xs[1][yg * RY + t][pc];
                 }
                 NDWT_SFOR(i, RY)
-                    v2 acc = (v2)(T(0));
-                    NDWT_UNROLL
-                    for (int j = 0; j < L; ++j) {
-                        acc += tp.lo[1][j] * av[i + j];
-                        acc += tp.hi[1][j] * dv[i + j];
-                    }
-                    st.win[k][i][(R + L - 1) % L] = acc;
+                    NDWT_SFOR(sub, CH)
+                        v2 acc = (v2)(T(0));
+                        NDWT_UNROLL
+                        for (int j = 0; j < L; ++j) {
+                            acc += tp.lo[1][j] * LD::get(av[i + j], sub);
+                            acc += tp.hi[1][j] * LD::get(dv[i + j], sub);
+                        }
+                        st.win[k][i * CH + sub][(R + L - 1) % L] = acc;
+                    NDWT_SEND
                 NDWT_SEND
                 if (emit) {
-                    int gx = tc.x0 + x;
+                    int gx = tc.x0 + cx * CH;
                     NDWT_SFOR(i, RY)
-                        v2 acc = (v2)(T(0));
-                        NDWT_SFOR(j, L)
-                            v2 t = {tp.lo[2][j], tp.hi[2][j]};
-                            acc += t * st.win[k][i][(R + j) % L];
+                        T o[CH];
+                        NDWT_SFOR(sub, CH)
+                            v2 acc = (v2)(T(0));
+                            NDWT_SFOR(j, L)
+                                v2 t = {tp.lo[2][j], tp.hi[2][j]};
+                                acc += t * st.win[k][i * CH + sub][(R + j) % L];
+                            NDWT_SEND
+                            o[sub] = acc.x + acc.y;
                         NDWT_SEND
                         int gy = tc.y0 + yg * RY + i;
-                        if (gx < a.n1 && gy < a.n2)
-                            a.out[0][obase + (long long)z * a.plane + (long long)gy * a.n1 + gx] = acc.x + acc.y;
+                        if (gy < a.n2) {
+                            T* dst = a.out[0] + obase + (long long)z * a.plane + (long long)gy * a.n1 + gx;
+                            if constexpr (VEC4 && CH == 2) {
+                                if (gx < a.n1) *reinterpret_cast<v2*>(dst) = v2{o[0], o[CH - 1]};
+                            } else {
+                                NDWT_SFOR(sub, CH)
+                                    if (gx + sub < a.n1) dst[sub] = o[sub];
+                                NDWT_SEND
+                            }
+                        }
                     NDWT_SEND
                 }
             }
@@ -528,7 +626,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_> st
         const long long obase = (long long)tc.batch * a.out_bstride;
         const int nsteps = tc.zend - tc.zbeg;
         const int nplanes = nsteps + L - 1;              // planes zbeg-LH .. zend-1+RH
-        ex.each([&](int tid, State& st) {
+        ex.each([&](int tid, State& st) __attribute__((always_inline)) {
             setup(st, a, tc, tid);
             load_raw(st, a, ibase, tc.zbeg - LH, 0, tid);
         });
@@ -536,18 +634,252 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_> st
             const int zraw = tc.zbeg - LH + p;
             const int s = p - (L - 1);                   // output step this plane completes (if >= 0)
             for (int yb = 0; yb < 2; ++yb) {
-                ex.each([&](int tid, State& st) {
+                ex.each([&](int tid, State& st) __attribute__((always_inline)) {
                     stash_raw(st, sh, tid);
                     if (yb == 0) load_raw(st, a, ibase, zraw, 1, tid);
                     else if (p + 1 < nplanes) load_raw(st, a, ibase, zraw + 1, 0, tid);
                 });
                 ex.barrier();
-                ex.each([&](int tid, State&) { xsyn(sh, tp, yb, tid); });
+                ex.each([&](int tid, State&) __attribute__((always_inline)) { xsyn(sh, tp, yb, tid); });
                 ex.barrier();
             }
-            ex.each([&](int tid, State& st) {
+            ex.each([&](int tid, State& st) __attribute__((always_inline)) {
                 // plane p lives in slot p%L; rotation R puts the newest into (R+L-1)%L -> R = (p+1)%L
                 yzdispatch<0>((p + 1) % L, st, sh, tp, a, tc, obase, tc.zbeg + s, s >= 0, tid);
+            });
+        }
+    }
+};
+
+// ------------------------------------------------------------------- synthesis, lane-shift form ----
+// Same arithmetic as Inv3 with a different data path: the x-synthesis takes its x neighbours straight from the
+// adjacent lanes' registers (DPP wave shifts) instead of a raw tile in LDS.  A wave holds whole haloed rows
+// (NG = TX/4 + halo groups lanes per row, RPW rows per wave), every lane loads 4 x of all 2^3 bands of one row.
+// LDS only carries the x-synthesised tile, double buffered: ONE barrier per plane and no y-bit phases.
+//   per plane:  x-synth(p) from registers -> xs[p&1] ; prefetch raw(p+1) ; barrier ; y-synth + z-synth(p) from xs[p&1]
+#ifdef NDWT_HOST_EMU
+#define NDWT_LANE_SHIFT(ex, tid, D, expr_of_s) ((ex).template peer_value<D>((tid), [&](const State& s) { return (expr_of_s); }))
+#else
+template <typename T> __device__ __forceinline__ T dpp_shr1(T v);   // lane i <- lane i-1 (0 into lane 0)
+template <typename T> __device__ __forceinline__ T dpp_shl1(T v);   // lane i <- lane i+1
+template <> __device__ __forceinline__ float dpp_shr1<float>(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, true));
+}
+template <> __device__ __forceinline__ float dpp_shl1<float>(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
+}
+template <> __device__ __forceinline__ double dpp_shr1<double>(double v) {
+    long long b = __builtin_bit_cast(long long, v);
+    int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x138, 0xF, 0xF, true);
+    int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x138, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <> __device__ __forceinline__ double dpp_shl1<double>(double v) {
+    long long b = __builtin_bit_cast(long long, v);
+    int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x130, 0xF, 0xF, true);
+    int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x130, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+// value of `v` in lane (i + D)
+template <int D, typename T> __device__ __forceinline__ T lane_shift(T v) {
+    if constexpr (D == 0) return v;
+    else if constexpr (D < 0) return lane_shift<D + 1>(dpp_shr1<T>(v));
+    else return lane_shift<D - 1>(dpp_shl1<T>(v));
+}
+#define NDWT_LANE_SHIFT(ex, tid, D, expr_of_s) (lane_shift<D>([&](const State& s) { return (expr_of_s); }(st)))
+#endif
+
+template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, int WPE_ = 2> struct Inv3S {
+    static constexpr int L = L_, TX = TX_, TY = TY_, NT = NT_, RY = RY_;
+    static constexpr bool VEC4 = VEC4_;
+    static constexpr int NE = VEC4 ? 1 : 4;
+    static constexpr int WPE = WPE_;
+    static constexpr int LH = L / 2, RH = L / 2 - 1;
+    static constexpr int GL = (LH + 3) / 4, GR = (RH + 3) / 4;
+    static constexpr int NG = TX / 4 + GL + GR;          // lanes per haloed row
+    static constexpr int NR = TY + L - 1;
+    static constexpr int RPW = 64 / NG;                  // rows per wave
+    static constexpr int NW = NT / 64;
+    static constexpr int RPR = RPW * NW;                 // rows per round
+    static constexpr int NRND = (NR + RPR - 1) / RPR;
+    typedef Lds<T> LD;
+    static constexpr int CH = LD::CH;
+    static constexpr int TXC = TX / CH;
+    static constexpr int YITEMS = TXC * (TY / RY);
+    static constexpr int NYI = (YITEMS + NT - 1) / NT;
+    static constexpr int NP = CH * RY;
+    static constexpr int XV = 4 * (1 + GL + GR);
+    static_assert(TX % 4 == 0 && TY % RY == 0 && L % 2 == 0 && NT % 64 == 0 && RPW >= 1, "tile shape");
+    typedef typename VecT<T>::v2 v2;
+    typedef typename VecT<T>::v4 v4;
+    typedef typename LD::chunk chunk;
+    typedef Taps3<T, L> Taps;
+    typedef Fused3Args<T> Args;
+
+    struct Shared {
+        chunk xs[2][2][NR][TXC];   // [buffer][y-bit][row][x] of (z-bit 0, z-bit 1)
+    };
+    struct State {
+        T zacc[NYI][L][NP];        // z-synthesis in scatter form: partial sums of the next L output planes, rotating
+        v4 raw[NRND][8];           // 4 x of every band of this lane's row(s); refilled as soon as consumed
+        int off[NRND][NE];
+    };
+
+    static NDWT_DEV void lane_item(int tid, int rnd, int& ug, int& r, bool& valid) {
+        const int lane = tid % 64, wv = tid / 64;
+        int rs = lane / NG;
+        ug = lane % NG;
+        r = rnd * RPR + wv * RPW + rs;
+        valid = rs < RPW && r < NR;
+        if (rs >= RPW) rs = RPW - 1;
+        if (r >= NR) r = NR - 1;
+    }
+
+    static NDWT_DEV void setup(State& st, const Args& a, const TileCoord& tc, int tid) {
+        NDWT_SFOR(k, NRND)
+            int ug, r;
+            bool valid;
+            lane_item(tid, k, ug, r, valid);
+            int y = modn(tc.y0 - LH + r, a.n2);
+            int xb = tc.x0 - 4 * GL + 4 * ug;
+            if (a.dbg & 1) { y = modn(tc.y0 + r % TY, a.n2); xb = tc.x0 + 4 * (ug % (TX / 4)); }
+            NDWT_SFOR(e, NE)
+                st.off[k][e] = y * a.n1 + modn(xb + e, a.n1);
+            NDWT_SEND
+        NDWT_SEND
+    }
+
+    static NDWT_DEV void load_raw(State& st, const Args& a, long long ibase, int zraw) {
+        long long zm = a.z_wrap ? (long long)modn(zraw, a.n3) : (long long)(zraw + LH);
+        long long pb = ibase + zm * a.plane;
+        NDWT_SFOR(k, NRND)
+            NDWT_SFOR(b, 8)
+                const T* p = a.in[b] + pb;
+                if constexpr (VEC4) {
+                    st.raw[k][b] = *reinterpret_cast<const v4*>(p + st.off[k][0]);
+                } else {
+                    NDWT_SFOR(e, NE)
+                        st.raw[k][b][e] = p[st.off[k][e]];
+                    NDWT_SEND
+                }
+            NDWT_SEND
+        NDWT_SEND
+    }
+
+    // all 64 lanes of every wave execute the shifts (no divergence before them); only the LDS store is predicated
+    template <class Exec> static NDWT_DEV void xsyn(Exec& ex, State& st, Shared& sh, const Taps& tp, int buf, int tid) {
+        NDWT_SFOR(k, NRND)
+            int ug, r;
+            bool valid;
+            lane_item(tid, k, ug, r, valid);
+            NDWT_SFOR(yb, 2)
+                v2 acc[4];
+                acc[0] = acc[1] = acc[2] = acc[3] = (v2)(T(0));
+                NDWT_SFOR(i, XV)                          // window element i <-> x offset i - 4*GL from this lane's first x
+                    constexpr int D = i / 4 - GL;         // lane distance
+                    constexpr int c = i % 4;
+                    // (z-bit 0, z-bit 1) of the low-pass (x-bit 0) and high-pass (x-bit 1) inputs
+                    v2 wa = {NDWT_LANE_SHIFT(ex, tid, D, s.raw[k][0 + 2 * yb][c]), NDWT_LANE_SHIFT(ex, tid, D, s.raw[k][4 + 2 * yb][c])};
+                    v2 wd = {NDWT_LANE_SHIFT(ex, tid, D, s.raw[k][1 + 2 * yb][c]), NDWT_LANE_SHIFT(ex, tid, D, s.raw[k][5 + 2 * yb][c])};
+                    NDWT_SFOR(e, 4)
+                        constexpr int j = i - (4 * GL + e - LH);
+                        if constexpr (j >= 0 && j < L) {
+                            acc[e] += tp.lo[0][j] * wa;
+                            acc[e] += tp.hi[0][j] * wd;
+                        }
+                    NDWT_SEND
+                NDWT_SEND
+                if (valid && ug >= GL && ug < GL + TX / 4) lds_store_run<T, 4>(sh.xs[buf][yb][r], 4 * (ug - GL), acc);
+            NDWT_SEND
+        NDWT_SEND
+    }
+
+    // y-synthesis of the newest plane (pairs P = (a, d)), then z-synthesis in scatter form: P adds tap j into the
+    // partial sum of output plane (newest - j); rotation R keeps that sum in slot (R-1-j) mod L, the j = 0 slot is
+    // (re)initialised and the j = L-1 slot completes output plane z.  (L-1 floats of state per position instead
+    // of the L pairs a gather window needs.)
+    template <int R>
+    static NDWT_DEV void yzsyn(State& st, Shared& sh, const Taps& tp, const Args& a, const TileCoord& tc, long long obase,
+                               int z, bool emit, int buf, int tid) {
+        NDWT_SFOR(k, NYI)
+            int it = tid + k * NT;
+            if (it < YITEMS) {
+                int cx = it % TXC, yg = it / TXC;
+                const int pc = LD::S(cx);
+                v2 P[NP];
+                NDWT_SFOR(q, NP)
+                    P[q] = (v2)(T(0));
+                NDWT_SEND
+                NDWT_SFOR(yb, 2)
+                    chunk cv[RY + L - 1];
+                    NDWT_SFOR(t, RY + L - 1)
+                        cv[t] = sh.xs[buf][yb][yg * RY + t][pc];
+                    NDWT_SEND
+                    NDWT_SFOR(i, RY)
+                        NDWT_SFOR(sub, CH)
+                            NDWT_SFOR(j, L)
+                                if constexpr (yb == 0) P[i * CH + sub] += tp.lo[1][j] * LD::get(cv[i + j], sub);
+                                else P[i * CH + sub] += tp.hi[1][j] * LD::get(cv[i + j], sub);
+                            NDWT_SEND
+                        NDWT_SEND
+                    NDWT_SEND
+                NDWT_SEND
+                NDWT_SFOR(q, NP)
+                    NDWT_SFOR(j, L)
+                        constexpr int slot = ((R - 1 - j) % L + L) % L;
+                        const T c = tp.lo[2][j] * P[q].x + tp.hi[2][j] * P[q].y;
+                        if constexpr (j == 0) st.zacc[k][slot][q] = c;
+                        else st.zacc[k][slot][q] += c;
+                    NDWT_SEND
+                NDWT_SEND
+                if (emit) {
+                    constexpr int done = ((R - L) % L + L) % L;
+                    int gx = tc.x0 + cx * CH;
+                    NDWT_SFOR(i, RY)
+                        int gy = tc.y0 + yg * RY + i;
+                        if (gy < a.n2) {
+                            T* dst = a.out[0] + obase + (long long)z * a.plane + (long long)gy * a.n1 + gx;
+                            if constexpr (VEC4 && CH == 2) {
+                                if (gx < a.n1) *reinterpret_cast<v2*>(dst) = v2{st.zacc[k][done][i * CH], st.zacc[k][done][i * CH + CH - 1]};
+                            } else {
+                                NDWT_SFOR(sub, CH)
+                                    if (gx + sub < a.n1) dst[sub] = st.zacc[k][done][i * CH + sub];
+                                NDWT_SEND
+                            }
+                        }
+                    NDWT_SEND
+                }
+            }
+        NDWT_SEND
+    }
+    template <int R>
+    static NDWT_DEV void yzdispatch(int r, State& st, Shared& sh, const Taps& tp, const Args& a, const TileCoord& tc,
+                                    long long obase, int z, bool emit, int buf, int tid) {
+        if constexpr (R < L) {
+            if (r == R) yzsyn<R>(st, sh, tp, a, tc, obase, z, emit, buf, tid);
+            else yzdispatch<R + 1>(r, st, sh, tp, a, tc, obase, z, emit, buf, tid);
+        }
+    }
+
+    template <class Exec> static NDWT_DEV void block(Exec& ex, Shared& sh, const Args& a, const Taps& tp, int bid) {
+        const TileCoord tc = decode_tile(a, bid, TX, TY);
+        const long long ibase = (long long)tc.batch * a.in_bstride;
+        const long long obase = (long long)tc.batch * a.out_bstride;
+        const int nsteps = tc.zend - tc.zbeg;
+        const int nplanes = nsteps + L - 1;              // planes zbeg-LH .. zend-1+RH
+        ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+            setup(st, a, tc, tid);
+            load_raw(st, a, ibase, tc.zbeg - LH);
+        });
+        for (int p = 0; p < nplanes; ++p) {
+            const int s = p - (L - 1);
+            ex.each([&](int tid, State& st) __attribute__((always_inline)) { xsyn(ex, st, sh, tp, p & 1, tid); });
+            ex.each([&](int, State& st) __attribute__((always_inline)) {                 // (separate pass only matters to the host emulator)
+                if (p + 1 < nplanes) load_raw(st, a, ibase, tc.zbeg - LH + p + 1);
+            });
+            ex.barrier();
+            ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+                yzdispatch<0>((p + 1) % L, st, sh, tp, a, tc, obase, tc.zbeg + s, s >= 0, p & 1, tid);
             });
         }
     }

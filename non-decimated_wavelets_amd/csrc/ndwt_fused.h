@@ -15,9 +15,12 @@ struct FusedTapsD {       // per axis (0 = x, 1 = y, 2 = z), zero-padded to Lp, 
     double hi[3][kMaxTaps];
 };
 
-int launch_fwd3_f32(const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, hipStream_t s);
-int launch_inv3_f32(const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, hipStream_t s);
-int launch_fwd3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4, hipStream_t s);
-int launch_inv3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4, hipStream_t s);
+// tile shape a variant uses (for the launch geometry)
+void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int* TY);
+
+int launch_fwd3_f32(const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, int variant, const void* taps_dev, hipStream_t s);
+int launch_inv3_f32(const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, int variant, const void* taps_dev, hipStream_t s);
+int launch_fwd3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4, int variant, const void* taps_dev, hipStream_t s);
+int launch_inv3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4, int variant, const void* taps_dev, hipStream_t s);
 
 }  // namespace ndwt

@@ -5,47 +5,60 @@
 namespace ndwt {
 
 template <class State> struct GpuExec {
+    typedef State state_type;
     State st;
-    template <class F> __device__ __forceinline__ void each(F&& f) { f((int)threadIdx.x, st); }
+    template <class F> __device__ __forceinline__ void each(F&& f) { f((int)threadIdx.x, st); }   // (callers pass always-inline lambdas)
     __device__ __forceinline__ void barrier() { __syncthreads(); }
 };
 
+// amdgpu_waves_per_eu pins the register budget: without it hipcc aims at the LDS-limited occupancy and spills the
+// filter windows to scratch (512-thread workgroups: 65 VGPRs + 176 B/lane of scratch).
+// The taps live in a small device buffer owned by the plan and are read through the CONSTANT address space, so
+// every tap is a scalar load into SGPRs (a by-value struct argument ends up partly in scratch once the stage
+// functions nest a few lambdas deep).
 template <class K>
-__global__ __launch_bounds__(K::NT) void fused3_kernel(const typename K::Args a, const typename K::Taps tp) {
+__global__ __launch_bounds__(K::NT) __attribute__((amdgpu_waves_per_eu(K::WPE, K::WPE))) void fused3_kernel(
+    const typename K::Args a, const typename K::Taps* __restrict__ taps_global) {
     __shared__ typename K::Shared sh;
     GpuExec<typename K::State> ex;
+    typedef const __attribute__((address_space(4))) typename K::Taps* ctaps_ptr;
+    const typename K::Taps& tp = *(const typename K::Taps*)(ctaps_ptr)taps_global;
     K::block(ex, sh, a, tp, (int)blockIdx.x);
 }
 
-template <class K> int launch_fused3(const typename K::Args& a, const FusedTapsD& t, hipStream_t s) {
-    typename K::Taps tp;
-    for (int ax = 0; ax < 3; ++ax)
-        for (int j = 0; j < K::L; ++j) {
-            tp.lo[ax][j] = (decltype(tp.lo[0][0] + 0))t.lo[ax][j];
-            tp.hi[ax][j] = (decltype(tp.hi[0][0] + 0))t.hi[ax][j];
-        }
+// taps_dev: device buffer holding Taps3<T, Lp> (lo[3][Lp] then hi[3][Lp]) for this direction
+template <class K> int launch_fused3(const typename K::Args& a, const FusedTapsD& t, const void* taps_dev, hipStream_t s) {
+    (void)t;
     const int nblocks = a.ntx * a.nty * a.nzc * a.nbatch;
-    hipLaunchKernelGGL(fused3_kernel<K>, dim3(nblocks), dim3(K::NT), 0, s, a, tp);
+    hipLaunchKernelGGL(fused3_kernel<K>, dim3(nblocks), dim3(K::NT), 0, s, a, (const typename K::Taps*)taps_dev);
     return (int)hipGetLastError();
 }
 
-// NDWT_FUSED_SWITCH(KIND, T): dispatch on padded length and vector path
-#define NDWT_FUSED_CASE(KIND, T, LL)                                                                         \
-    case LL:                                                                                                 \
-        return vec4 ? launch_fused3<KIND<T, LL, Fused3Tile<T>::TX, Fused3Tile<T>::TY, Fused3Tile<T>::NT,      \
-                                         Fused3Tile<T>::RY, true>>(a, t, s)                                  \
-                    : launch_fused3<KIND<T, LL, Fused3Tile<T>::TX, Fused3Tile<T>::TY, Fused3Tile<T>::NT,      \
-                                         Fused3Tile<T>::RY, false>>(a, t, s);
+// dispatch on variant, padded tap length and vector path
+#define NDWT_FUSED_K(KIND, INV, T, LL, V, VEC)                                                               \
+    KIND<T, LL, Fused3Tile<T, INV, V>::TX, Fused3Tile<T, INV, V>::TY, Fused3Tile<T, INV, V>::NT,             \
+         Fused3Tile<T, INV, V>::RY, VEC, Fused3Tile<T, INV, V>::WPE>
 
-#define NDWT_FUSED_SWITCH(KIND, T)        \
-    switch (t.Lp) {                       \
-        NDWT_FUSED_CASE(KIND, T, 2)       \
-        NDWT_FUSED_CASE(KIND, T, 4)       \
-        NDWT_FUSED_CASE(KIND, T, 6)       \
-        NDWT_FUSED_CASE(KIND, T, 8)       \
-        NDWT_FUSED_CASE(KIND, T, 10)      \
-        NDWT_FUSED_CASE(KIND, T, 12)      \
-        default: return -1;               \
+#define NDWT_FUSED_CASE(KIND, INV, T, LL, V)                                                                  \
+    case LL:                                                                                                 \
+        return vec4 ? launch_fused3<NDWT_FUSED_K(KIND, INV, T, LL, V, true)>(a, t, taps_dev, s)                        \
+                    : launch_fused3<NDWT_FUSED_K(KIND, INV, T, LL, V, false)>(a, t, taps_dev, s);
+
+#define NDWT_FUSED_SWITCH_V(KIND, INV, T, V)  \
+    switch (t.Lp) {                            \
+        NDWT_FUSED_CASE(KIND, INV, T, 2, V)    \
+        NDWT_FUSED_CASE(KIND, INV, T, 4, V)    \
+        NDWT_FUSED_CASE(KIND, INV, T, 6, V)    \
+        NDWT_FUSED_CASE(KIND, INV, T, 8, V)    \
+        NDWT_FUSED_CASE(KIND, INV, T, 10, V)   \
+        NDWT_FUSED_CASE(KIND, INV, T, 12, V)   \
+        default: return -1;                    \
     }
+
+// float: all variants for db4 experiments; others: variant 0
+#define NDWT_FUSED_SWITCH(KIND, KINDV, INV, T)                            \
+    if (variant == 1 && t.Lp == 8) { switch (t.Lp) { NDWT_FUSED_CASE(KINDV, INV, T, 8, 1) } }  \
+    if (variant == 2 && t.Lp == 8) { switch (t.Lp) { NDWT_FUSED_CASE(KINDV, INV, T, 8, 2) } }  \
+    NDWT_FUSED_SWITCH_V(KIND, INV, T, 0)
 
 }  // namespace ndwt

@@ -18,6 +18,13 @@ namespace {
 template <class State, int NT> struct EmuExec {
     std::vector<State> st;
     EmuExec() : st(NT) {}
+    // value an expression takes in lane (tid + D) of the same 64-lane wave (0 outside it): what the DPP wave
+    // shifts deliver on the GPU
+    template <int D, class G> auto peer_value(int tid, G&& getter) -> decltype(getter(st[0])) {
+        const int lane = tid % 64 + D;
+        if (lane < 0 || lane > 63) return decltype(getter(st[0]))(0);
+        return getter(st[tid + D]);
+    }
     template <class F> void each(F&& f) {
         for (int tid = 0; tid < NT; ++tid) f(tid, st[tid]);
     }
@@ -42,12 +49,12 @@ int run(ndwt::Fused3Args<T>& a, const double* lo, const double* hi) {
     return 0;
 }
 
-template <typename T, template <typename, int, int, int, int, int, bool> class KIND, int TX, int TY, int NT, int RY, bool ALL>
+template <typename T, template <typename, int, int, int, int, int, bool, int> class KIND, int TX, int TY, int NT, int RY, bool ALL>
 int dispatch(int Lp, int vec4, ndwt::Fused3Args<T>& a, const double* lo, const double* hi) {
 #define CASE(LL)                                                              \
     case LL:                                                                  \
-        return vec4 ? run<KIND<T, LL, TX, TY, NT, RY, true>, T>(a, lo, hi)    \
-                    : run<KIND<T, LL, TX, TY, NT, RY, false>, T>(a, lo, hi);
+        return vec4 ? run<KIND<T, LL, TX, TY, NT, RY, true, 2>, T>(a, lo, hi)    \
+                    : run<KIND<T, LL, TX, TY, NT, RY, false, 2>, T>(a, lo, hi);
     if constexpr (ALL) {
         switch (Lp) {
             CASE(2) CASE(4) CASE(6) CASE(8) CASE(12)
@@ -64,7 +71,7 @@ int dispatch(int Lp, int vec4, ndwt::Fused3Args<T>& a, const double* lo, const d
 
 template <typename T>
 int emu3(int inverse, int Lp, int vec4, const T* in, T* out, int n1, int n2, int n3, int nbatch, int zchunk,
-         const double* lo, const double* hi, int z_wrap, int small_tile) {
+         const double* lo, const double* hi, int z_wrap, int small_tile, int variant) {
     ndwt::Fused3Args<T> a;
     std::memset(&a, 0, sizeof(a));
     a.n1 = n1; a.n2 = n2; a.n3 = n3; a.nbatch = nbatch;
@@ -83,13 +90,23 @@ int emu3(int inverse, int Lp, int vec4, const T* in, T* out, int n1, int n2, int
     }
     if (small_tile) {   // a second tile shape exercises different item/lane mappings
         ndwt::fused3_geometry(a, 16, 8, Lp, 2048, zchunk);
+        if (variant == 2 && inverse)   // lane-shift synthesis on the small tile, every tap length
+            return dispatch<T, ndwt::Inv3S, 16, 8, 128, 2, true>(Lp, vec4, a, lo, hi);
         return inverse ? dispatch<T, ndwt::Inv3, 16, 8, 64, 2, true>(Lp, vec4, a, lo, hi)
                        : dispatch<T, ndwt::Fwd3, 16, 8, 64, 2, true>(Lp, vec4, a, lo, hi);
     }
-    typedef ndwt::Fused3Tile<T> P;   // the tile shape the library launches
-    ndwt::fused3_geometry(a, P::TX, P::TY, Lp, 2048, zchunk);
-    return inverse ? dispatch<T, ndwt::Inv3, P::TX, P::TY, P::NT, P::RY, false>(Lp, vec4, a, lo, hi)
-                   : dispatch<T, ndwt::Fwd3, P::TX, P::TY, P::NT, P::RY, false>(Lp, vec4, a, lo, hi);
+    // the tile shapes the library launches (variant `small_tile`-2... 0 = default)
+    typedef ndwt::Fused3Tile<T, false, 0> PF;
+    typedef ndwt::Fused3Tile<T, true, 0> PI;
+    typedef ndwt::Fused3Tile<T, false, 1> PF1;
+    typedef ndwt::Fused3Tile<T, true, 1> PI1;
+    ndwt::fused3_geometry(a, PF::TX, PF::TY, Lp, 2048, zchunk);
+    if (variant == 1 && inverse) ndwt::fused3_geometry(a, PI1::TX, PI1::TY, Lp, 2048, zchunk);
+    if (variant == 1)
+        return inverse ? dispatch<T, ndwt::Inv3S, PI1::TX, PI1::TY, PI1::NT, PI1::RY, false>(Lp, vec4, a, lo, hi)
+                       : dispatch<T, ndwt::Fwd3, PF1::TX, PF1::TY, PF1::NT, PF1::RY, false>(Lp, vec4, a, lo, hi);
+    return inverse ? dispatch<T, ndwt::Inv3, PI::TX, PI::TY, PI::NT, PI::RY, false>(Lp, vec4, a, lo, hi)
+                   : dispatch<T, ndwt::Fwd3, PF::TX, PF::TY, PF::NT, PF::RY, false>(Lp, vec4, a, lo, hi);
 }
 
 }  // namespace
@@ -97,11 +114,11 @@ int emu3(int inverse, int Lp, int vec4, const T* in, T* out, int n1, int n2, int
 extern "C" {
 // in/out: band-planar, batch inside band: [band][batch][n3(+halo)][n2][n1]; lo/hi: [3][20] padded kernel-form taps
 int ndwt_emu3_f32(int inverse, int Lp, int vec4, const float* in, float* out, int n1, int n2, int n3, int nbatch,
-                  int zchunk, const double* lo, const double* hi, int z_wrap, int small_tile) {
-    return emu3<float>(inverse, Lp, vec4, in, out, n1, n2, n3, nbatch, zchunk, lo, hi, z_wrap, small_tile);
+                  int zchunk, const double* lo, const double* hi, int z_wrap, int small_tile, int variant) {
+    return emu3<float>(inverse, Lp, vec4, in, out, n1, n2, n3, nbatch, zchunk, lo, hi, z_wrap, small_tile, variant);
 }
 int ndwt_emu3_f64(int inverse, int Lp, int vec4, const double* in, double* out, int n1, int n2, int n3, int nbatch,
-                  int zchunk, const double* lo, const double* hi, int z_wrap, int small_tile) {
-    return emu3<double>(inverse, Lp, vec4, in, out, n1, n2, n3, nbatch, zchunk, lo, hi, z_wrap, small_tile);
+                  int zchunk, const double* lo, const double* hi, int z_wrap, int small_tile, int variant) {
+    return emu3<double>(inverse, Lp, vec4, in, out, n1, n2, n3, nbatch, zchunk, lo, hi, z_wrap, small_tile, variant);
 }
 }

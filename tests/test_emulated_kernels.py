@@ -28,7 +28,7 @@ def emu():
     return ctypes.CDLL(EMU_SO)
 
 
-def _run(emu, x_mat_or_bands, wnames, l2, inverse, dtype, vec4, zchunk, small, z_wrap=1):
+def _run(emu, x_mat_or_bands, wnames, l2, inverse, dtype, vec4, zchunk, small, z_wrap=1, variant=0):
     Ls = [len(orc.wave_filters(w)[0]) for w in wnames]
     Lp = max(Ls)
     lo = np.zeros((3, 20))
@@ -48,7 +48,7 @@ def _run(emu, x_mat_or_bands, wnames, l2, inverse, dtype, vec4, zchunk, small, z
     fn.restype = ctypes.c_int
     rc = fn(int(inverse), Lp, int(vec4), src.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p),
             n1, n2, n3, 1, zchunk, lo.ctypes.data_as(ctypes.c_void_p), hi.ctypes.data_as(ctypes.c_void_p), z_wrap,
-            int(small))
+            int(small), int(variant))
     assert rc == 0
     return np.transpose(out)
 
@@ -72,9 +72,10 @@ def test_emulated_fused3_analysis(emu, sizes, wn, vec4, zchunk, small, l2):
     filt = [orc.wave_filters(w) for w in wn]
     want = orc.spatial_level_dec(x, filt, l2)
     for dtype, tol in ((np.float64, 1e-13), (np.float32, 2e-6)):
-        got = _run(emu, x, wn, l2, False, dtype, vec4, zchunk, small)
-        assert np.isfinite(got).all()
-        assert np.abs(got - want).max() <= tol * np.abs(want).max()
+        for variant in ((0, 1) if not small and dtype == np.float32 else (0,)):
+            got = _run(emu, x, wn, l2, False, dtype, vec4, zchunk, small, variant=variant)
+            assert np.isfinite(got).all()
+            assert np.abs(got - want).max() <= tol * np.abs(want).max()
 
 
 @pytest.mark.slow
@@ -86,6 +87,8 @@ def test_emulated_fused3_synthesis(emu, sizes, wn, vec4, zchunk, small, l2):
     filt = [orc.wave_filters(w) for w in wn]
     want = orc.spatial_level_rec(c, filt, l2)
     for dtype, tol in ((np.float64, 1e-13), (np.float32, 2e-6)):
-        got = _run(emu, c, wn, l2, True, dtype, vec4, zchunk, small)
-        assert np.isfinite(got).all()
-        assert np.abs(got - want).max() <= tol * max(np.abs(want).max(), 1.0)
+        # variants 1 (production tile, float) and 2 (small tile, every tap length) are the lane-shift synthesis kernel
+        for variant in ((0, 1) if not small and dtype == np.float32 else (0, 2) if small else (0,)):
+            got = _run(emu, c, wn, l2, True, dtype, vec4, zchunk, small, variant=variant)
+            assert np.isfinite(got).all()
+            assert np.abs(got - want).max() <= tol * max(np.abs(want).max(), 1.0)
