@@ -111,6 +111,14 @@ int ndwt_slab_halo(const ndwt_plan* plan, int stride, int64_t* ana_before, int64
                    int64_t* syn_before, int64_t* syn_after);
 int ndwt_analysis_level_slab(ndwt_plan* plan, const void* in_with_halo, void* const* out_bands, int stride, void* stream);
 int ndwt_synthesis_level_slab(ndwt_plan* plan, const void* const* in_bands_with_halo, void* out, int stride, void* stream);
+/* Copy-free forms for fused 3-D plans (NDWT_ERR_UNSUPPORTED otherwise; the outer-axis filter must be the longest):
+ * analysis reads the local slab and the two halo buffers (as received from the neighbours) from separate pointers;
+ * synthesis treats the local coefficient slab as zero outside and writes syn_after + local + syn_before planes:
+ * the local result plus the partial sums owed to the neighbouring slabs (they are sent there and added -- 1 band of
+ * exchange instead of the halo of all 2^d bands). */
+int ndwt_analysis_level_slab_split(ndwt_plan* plan, const void* in_local, const void* halo_before, const void* halo_after,
+                                   void* const* out_bands, int stride, void* stream);
+int ndwt_synthesis_level_slab_ext(ndwt_plan* plan, const void* const* in_bands_local, void* out_ext, int stride, void* stream);
 
 /* ---- errors ------------------------------------------------------------------------------------------ */
 const char* ndwt_last_error(void); /* thread-local message of the last failing call */

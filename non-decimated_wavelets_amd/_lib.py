@@ -22,7 +22,8 @@ NDWT_PATH_AUTO, NDWT_PATH_GENERIC = 0, 1
 EXPORTS = [
     "ndwt_wave_filters", "ndwt_num_bands", "ndwt_level_from_bands", "ndwt_plan_create", "ndwt_plan_destroy",
     "ndwt_plan_set_path", "ndwt_plan_describe", "ndwt_plan_set_tuning", "ndwt_plan_set_profiling", "ndwt_plan_get_profile", "ndwt_dec", "ndwt_rec", "ndwt_dec_host",
-    "ndwt_rec_host", "ndwt_slab_halo", "ndwt_analysis_level_slab", "ndwt_synthesis_level_slab", "ndwt_last_error",
+    "ndwt_rec_host", "ndwt_slab_halo", "ndwt_analysis_level_slab", "ndwt_synthesis_level_slab",
+    "ndwt_analysis_level_slab_split", "ndwt_synthesis_level_slab_ext", "ndwt_last_error",
     "ndwt_version",
 ]
 
@@ -79,6 +80,9 @@ def lib() -> ctypes.CDLL:
     L.ndwt_slab_halo.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.POINTER(ctypes.c_int64)] * 4
     L.ndwt_analysis_level_slab.argtypes = [ctypes.c_void_p, ctypes.c_void_p, c_void_pp, ctypes.c_int, ctypes.c_void_p]
     L.ndwt_synthesis_level_slab.argtypes = [ctypes.c_void_p, c_void_pp, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    L.ndwt_analysis_level_slab_split.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_void_pp,
+                                                 ctypes.c_int, ctypes.c_void_p]
+    L.ndwt_synthesis_level_slab_ext.argtypes = [ctypes.c_void_p, c_void_pp, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     L.ndwt_last_error.restype = ctypes.c_char_p
     L.ndwt_version.restype = ctypes.c_char_p
     _lib = L

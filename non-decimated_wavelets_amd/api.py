@@ -92,6 +92,15 @@ class Plan:
         arr = (ctypes.c_void_p * len(out_ptrs))(*out_ptrs)
         L.check(L.lib().ndwt_analysis_level_slab(self._h, in_ptr, arr, int(stride), ctypes.c_void_p(stream)))
 
+    def analysis_level_slab_split(self, in_ptr, halo_before_ptr, halo_after_ptr, out_ptrs, stride=1, stream=0):
+        arr = (ctypes.c_void_p * len(out_ptrs))(*out_ptrs)
+        L.check(L.lib().ndwt_analysis_level_slab_split(self._h, in_ptr, halo_before_ptr, halo_after_ptr, arr, int(stride),
+                                                       ctypes.c_void_p(stream)))
+
+    def synthesis_level_slab_ext(self, in_ptrs, out_ext_ptr, stride=1, stream=0):
+        arr = (ctypes.c_void_p * len(in_ptrs))(*in_ptrs)
+        L.check(L.lib().ndwt_synthesis_level_slab_ext(self._h, arr, out_ext_ptr, int(stride), ctypes.c_void_p(stream)))
+
     def synthesis_level_slab(self, in_ptrs, out_ptr, stride=1, stream=0):
         arr = (ctypes.c_void_p * len(in_ptrs))(*in_ptrs)
         L.check(L.lib().ndwt_synthesis_level_slab(self._h, arr, out_ptr, int(stride), ctypes.c_void_p(stream)))

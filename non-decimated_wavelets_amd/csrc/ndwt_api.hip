@@ -233,7 +233,7 @@ void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int
 // one fused 3-D launch over `nbatch` volumes. n3 = output planes; z_wrap=false: inputs carry the z halo
 template <typename T>
 static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* in, T* const* out, long long n3, long long nbatch,
-                      long long in_bstride, long long out_bstride, bool z_wrap, hipStream_t s) {
+                      long long in_bstride, long long out_bstride, int z_mode, hipStream_t s) {
     Fused3Args<T> a;
     memset(&a, 0, sizeof a);
     a.n1 = (int)p->dims[0];
@@ -242,10 +242,10 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     a.nbatch = (int)nbatch;
     a.in_bstride = in_bstride;
     a.out_bstride = out_bstride;
-    a.z_wrap = z_wrap ? 1 : 0;
+    a.z_wrap = z_mode;
     if (const char* v = getenv("NDWT_DEBUG")) a.dbg = atoi(v);   // timing experiments only
     bool vec4 = (a.n1 % 4 == 0) && (in_bstride % 4 == 0) && (out_bstride % 4 == 0);
-    const int nin = inverse ? 8 : 1, nout = inverse ? 1 : 8;
+    const int nin = inverse ? 8 : (z_mode == 2 ? 3 : 1), nout = inverse ? 1 : 8;
     for (int b = 0; b < nin; ++b) { a.in[b] = in[b]; vec4 = vec4 && aligned_vec4<T>(in[b]); }
     for (int b = 0; b < nout; ++b) { a.out[b] = out[b]; vec4 = vec4 && aligned_vec4<T>(out[b]); }
     int TX = 0, TY = 0;
@@ -278,7 +278,7 @@ static int analysis_level(ndwt_plan* p, const T* in, T* const* out, long long st
         const long long vol3 = p->dims[0] * p->dims[1] * p->dims[2];
         if (d == 3) {
             const T* ins[8] = {in};
-            return fused3_run<T>(p, false, Lp, ins, out, p->dims[2], 1, vol_in, p->vol, !slab, s);
+            return fused3_run<T>(p, false, Lp, ins, out, p->dims[2], 1, vol_in, p->vol, slab ? 0 : 1, s);
         }
         // d == 4: outer axis per-axis (1 -> 2), then the fused 3-D kernel on both halves, batched over n4
         int rc = ensure_tmp(p, (size_t)(2 * p->vol) * sizeof(T));
@@ -289,9 +289,9 @@ static int analysis_level(ndwt_plan* p, const T* in, T* const* out, long long st
         if (rc) return rc;
         const T* ins_lo[8] = {lo};
         const T* ins_hi[8] = {hi};
-        rc = fused3_run<T>(p, false, Lp, ins_lo, out, p->dims[2], p->dims[3], vol3, vol3, true, s);
+        rc = fused3_run<T>(p, false, Lp, ins_lo, out, p->dims[2], p->dims[3], vol3, vol3, 1, s);
         if (rc) return rc;
-        return fused3_run<T>(p, false, Lp, ins_hi, out + 8, p->dims[2], p->dims[3], vol3, vol3, true, s);
+        return fused3_run<T>(p, false, Lp, ins_hi, out + 8, p->dims[2], p->dims[3], vol3, vol3, 1, s);
     }
     GenericCtx<T> c;
     c.p = p; c.stride = stride; c.slab = slab; c.s = s;
@@ -318,7 +318,7 @@ static int synthesis_level(ndwt_plan* p, const T* const* in, T* out, long long s
         const long long vol3 = p->dims[0] * p->dims[1] * p->dims[2];
         if (d == 3) {
             T* outs[8] = {out};
-            return fused3_run<T>(p, true, Lp, in, outs, p->dims[2], 1, vol_in, p->vol, !slab, s);
+            return fused3_run<T>(p, true, Lp, in, outs, p->dims[2], 1, vol_in, p->vol, slab ? 0 : 1, s);
         }
         int rc = ensure_tmp(p, (size_t)(2 * vol_in) * sizeof(T));
         if (rc) return rc;
@@ -326,9 +326,9 @@ static int synthesis_level(ndwt_plan* p, const T* const* in, T* out, long long s
         T* dd = a + vol_in;
         T* outs_a[8] = {a};
         T* outs_d[8] = {dd};
-        rc = fused3_run<T>(p, true, Lp, in, outs_a, p->dims[2], n_top_in, vol3, vol3, true, s);
+        rc = fused3_run<T>(p, true, Lp, in, outs_a, p->dims[2], n_top_in, vol3, vol3, 1, s);
         if (rc) return rc;
-        rc = fused3_run<T>(p, true, Lp, in + 8, outs_d, p->dims[2], n_top_in, vol3, vol3, true, s);
+        rc = fused3_run<T>(p, true, Lp, in + 8, outs_d, p->dims[2], n_top_in, vol3, vol3, 1, s);
         if (rc) return rc;
         return axis_pass<T>(p, true, 3, p->dims, stride, !slab, a, dd, out, nullptr, s);
     }
@@ -404,6 +404,27 @@ static int check_level(const ndwt_plan* p, int level) {
     }
     return NDWT_OK;
 }
+
+// fused 3-D slab forms that avoid haloed copies (multi-GPU fast path)
+static int slab_fast_ok(const ndwt_plan* p, int stride, int* Lp) {
+    if (!p) return fail(NDWT_ERR_INVALID_ARG, "null plan");
+    if (p->ndim != 3 || !fused3_eligible(p, stride, Lp) || p->filt[2].len != *Lp)
+        return fail(NDWT_ERR_UNSUPPORTED, "split/extended slab entry points need a fused 3-D plan whose outer-axis filter is the longest");
+    return NDWT_OK;
+}
+
+template <typename T>
+static int slab_split_impl(ndwt_plan* p, int Lp, const void* in, const void* hb, const void* ha, void* const* out, hipStream_t s) {
+    const T* ins[8] = {(const T*)in, (const T*)hb, (const T*)ha};
+    return fused3_run<T>(p, false, Lp, ins, (T* const*)out, p->dims[2], 1, p->vol, p->vol, 2, s);
+}
+
+template <typename T> static int slab_ext_impl(ndwt_plan* p, int Lp, const void* const* in, void* out, hipStream_t s) {
+    T* outs[8] = {(T*)out};
+    const long long n_out = p->dims[2] + (Lp - 1);
+    return fused3_run<T>(p, true, Lp, (const T* const*)in, outs, n_out, 1, p->vol, p->vol / p->dims[2] * n_out, 3, s);
+}
+
 
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" {
@@ -650,6 +671,28 @@ int ndwt_synthesis_level_slab(ndwt_plan* p, const void* const* in, void* out, in
     hipStream_t s = (hipStream_t)stream;
     return p->dtype == NDWT_F32 ? synthesis_level<float>(p, (const float* const*)in, (float*)out, stride, true, s)
                                 : synthesis_level<double>(p, (const double* const*)in, (double*)out, stride, true, s);
+}
+
+int ndwt_analysis_level_slab_split(ndwt_plan* p, const void* in_local, const void* halo_before, const void* halo_after,
+                                   void* const* out, int stride, void* stream) {
+    int Lp = 0;
+    int rc = slab_fast_ok(p, stride, &Lp);
+    if (rc) return rc;
+    if (!in_local || !out || (Lp > 2 && !halo_before) || !halo_after) return fail(NDWT_ERR_INVALID_ARG, "null pointer");
+    HIP_TRY(hipSetDevice(p->device));
+    if (!halo_before) halo_before = halo_after;   // db1: no plane before the slab is needed
+    return p->dtype == NDWT_F32 ? slab_split_impl<float>(p, Lp, in_local, halo_before, halo_after, out, (hipStream_t)stream)
+                                : slab_split_impl<double>(p, Lp, in_local, halo_before, halo_after, out, (hipStream_t)stream);
+}
+
+int ndwt_synthesis_level_slab_ext(ndwt_plan* p, const void* const* in_local, void* out_ext, int stride, void* stream) {
+    int Lp = 0;
+    int rc = slab_fast_ok(p, stride, &Lp);
+    if (rc) return rc;
+    if (!in_local || !out_ext) return fail(NDWT_ERR_INVALID_ARG, "null pointer");
+    HIP_TRY(hipSetDevice(p->device));
+    return p->dtype == NDWT_F32 ? slab_ext_impl<float>(p, Lp, in_local, out_ext, (hipStream_t)stream)
+                                : slab_ext_impl<double>(p, Lp, in_local, out_ext, (hipStream_t)stream);
 }
 
 const char* ndwt_last_error(void) { return g_last_error.c_str(); }

@@ -141,7 +141,9 @@ template <typename T> struct Fused3Args {
     long long plane;       // n1*n2
     int zchunk;            // output planes per workgroup
     int ntx, nty, nzc;     // tiles per axis
-    int z_wrap;            // 1: periodic in z; 0: inputs start `left` planes before local plane 0 (slab mode)
+    int z_wrap;            // outer axis: 1 periodic; 0 inputs start `left` planes before local plane 0 (haloed slab);
+                           // 2 analysis with separate halo buffers in[1] (before) / in[2] (after); 3 synthesis of the
+                           // zero-extended slab: n3 = n_in + L-1 output planes, inputs outside the slab read as 0
     int dbg;               // timing experiments only (wrong results): bit0 = fold halo reads back into the tile
 };
 
@@ -293,8 +295,15 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
     }
 
     static NDWT_DEV void load_plane(State& st, const Args& a, const T* inb, int zraw) {
-        long long zm = a.z_wrap ? (long long)modn(zraw, a.n3) : (long long)(zraw + LH);
-        const T* p = inb + zm * a.plane;
+        const T* p;
+        if (a.z_wrap == 2) {                             // halo planes live in their own (received) buffers
+            if (zraw < 0) p = a.in[1] + (long long)(zraw + LH) * a.plane;
+            else if (zraw >= a.n3) p = a.in[2] + (long long)(zraw - a.n3) * a.plane;
+            else p = inb + (long long)zraw * a.plane;
+        } else {
+            long long zm = a.z_wrap ? (long long)modn(zraw, a.n3) : (long long)(zraw + LH);
+            p = inb + zm * a.plane;
+        }
         NDWT_SFOR(k, NCOL)
             if constexpr (VEC4) {
                 st.nxt[k] = *reinterpret_cast<const v4*>(p + st.off[k][0]);
@@ -501,7 +510,17 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
 
     // issue the global loads of (plane zraw, y-bit yb) into st.pre
     static NDWT_DEV void load_raw(State& st, const Args& a, long long ibase, int zraw, int yb, int tid) {
-        long long zm = a.z_wrap ? (long long)modn(zraw, a.n3) : (long long)(zraw + LH);
+        long long zm = a.z_wrap == 1 ? (long long)modn(zraw, a.n3) : (long long)(zraw + LH);
+        if (a.z_wrap == 3) {                             // zero-extended slab: output plane k needs inputs k-(L-1)+j
+            zm = zraw - RH;
+            if (zm < 0 || zm >= a.n3 - (L - 1)) {
+                NDWT_SFOR(k, NLI)
+                    st.pre[k][0] = (v4)(T(0));
+                    st.pre[k][1] = (v4)(T(0));
+                NDWT_SEND
+                return;
+            }
+        }
         long long pb = ibase + zm * a.plane;
         NDWT_SFOR(k, NLI)
             int it = tid + k * NT;
@@ -750,7 +769,18 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
     }
 
     static NDWT_DEV void load_raw(State& st, const Args& a, long long ibase, int zraw) {
-        long long zm = a.z_wrap ? (long long)modn(zraw, a.n3) : (long long)(zraw + LH);
+        long long zm = a.z_wrap == 1 ? (long long)modn(zraw, a.n3) : (long long)(zraw + LH);
+        if (a.z_wrap == 3) {                             // zero-extended slab
+            zm = zraw - RH;
+            if (zm < 0 || zm >= a.n3 - (L - 1)) {
+                NDWT_SFOR(k, NRND)
+                    NDWT_SFOR(b, 8)
+                        st.raw[k][b] = (v4)(T(0));
+                    NDWT_SEND
+                NDWT_SEND
+                return;
+            }
+        }
         long long pb = ibase + zm * a.plane;
         NDWT_SFOR(k, NRND)
             NDWT_SFOR(b, 8)

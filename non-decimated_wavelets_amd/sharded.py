@@ -43,7 +43,10 @@ class HipSlabEngine:
         self.device = device
         self.dtype = dtype
         self.local_dims = list(local_dims)
-        self.supports_scatter = self.plan.describe() == "fused3d"
+        # split-halo analysis + zero-extended synthesis entry points (fused 3-D kernels only)
+        lens = [len(L.wave_filters(w)[0]) for w in wnames]
+        self.supports_scatter = (dilation == "reference" and len(local_dims) == 3 and self.plan.describe() == "fused3d"
+                                 and lens[2] == max(lens))
 
     def halo(self, stride):
         return self.plan.slab_halo(stride)

@@ -20,12 +20,13 @@ EMU_SO = os.path.join(ROOT, "tests", "emu", "libndwt_emu.so")
 
 @pytest.fixture(scope="module")
 def emu():
-    if not os.path.exists(EMU_SO):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "emu")])
-    # ASan must be loaded first when the host program (python) is not instrumented
-    if "libclang_rt.asan" not in os.environ.get("LD_PRELOAD", ""):
-        pytest.skip("run through tests/emu/run_emu_tests.sh (needs LD_PRELOAD of the ASan runtime)")
-    return ctypes.CDLL(EMU_SO)
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("clang++ of the ROCm toolchain is needed to build the host emulator")
+    # with the ASan runtime preloaded (tests/emu/run_emu_tests.sh) use the sanitizer build, else the plain one
+    asan = "libclang_rt.asan" in os.environ.get("LD_PRELOAD", "")
+    target = "libndwt_emu.so" if asan else "libndwt_emu_plain.so"
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), target])
+    return ctypes.CDLL(os.path.join(ROOT, "tests", "emu", target))
 
 
 def _run(emu, x_mat_or_bands, wnames, l2, inverse, dtype, vec4, zchunk, small, z_wrap=1, variant=0):

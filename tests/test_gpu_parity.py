@@ -262,3 +262,44 @@ def test_slab_entry_points_reproduce_the_periodic_transform():
                 r[z0:z0 + n3 // 2] = rk
             torch.cuda.synchronize()
             assert float((r - x).abs().max()) <= 10 * tol * float(x.abs().max())
+
+
+def test_copy_free_slab_entry_points_and_sharded_driver_on_one_gpu():
+    """split-halo analysis + zero-extended synthesis (the multi-GPU fast path) == the periodic transform"""
+    import importlib
+    api = importlib.import_module("non-decimated_wavelets_amd.api")
+    sh = importlib.import_module("non-decimated_wavelets_amd.sharded")
+    n1, n2, n3 = 72, 40, 48
+    for dtype, tol in ((torch.float64, 1e-12), (torch.float32, 2e-6)):
+        x = torch.randn(n3, n2, n1, device="cuda", dtype=dtype)
+        full = api.Plan([n1, n2, n3], ["db4"] * 3, dtype, pres_l2_norm=True, max_level=1)
+        y = torch.empty(8, n3, n2, n1, device="cuda", dtype=dtype)
+        full.dec(x.data_ptr(), y.data_ptr(), 1)
+        parts = [(0, 20), (20, 48)]                                  # uneven slabs
+        r_acc = torch.zeros(n3, n2, n1, device="cuda", dtype=dtype)
+        for z0, z1 in parts:
+            nl = z1 - z0
+            slab = api.Plan([n1, n2, nl], ["db4"] * 3, dtype, pres_l2_norm=True, max_level=1)
+            ab, aa, sb, sa = slab.slab_halo(1)
+            hb = x[torch.arange(z0 - ab, z0, device="cuda") % n3].contiguous()
+            ha = x[torch.arange(z1, z1 + aa, device="cuda") % n3].contiguous()
+            loc = x[z0:z1].contiguous()
+            outs = torch.empty(8, nl, n2, n1, device="cuda", dtype=dtype)
+            slab.analysis_level_slab_split(loc.data_ptr(), hb.data_ptr(), ha.data_ptr(), [outs[b].data_ptr() for b in range(8)], 1)
+            assert float((outs - y[:, z0:z1]).abs().max()) <= tol * float(y.abs().max())
+            ext = torch.empty(sa + nl + sb, n2, n1, device="cuda", dtype=dtype)
+            yl = y[:, z0:z1].contiguous()
+            slab.synthesis_level_slab_ext([yl[b].data_ptr() for b in range(8)], ext.data_ptr(), 1)
+            idx = torch.arange(z0 - sa, z1 + sb, device="cuda") % n3
+            r_acc.index_add_(0, idx, ext)                              # what the scatter-add exchange does
+        torch.cuda.synchronize()
+        assert float((r_acc - x).abs().max()) <= 20 * tol * float(x.abs().max())
+    # the driver itself with world size 1 (halo planes come from the own slab)
+    eng = sh.ShardedNdDwt(["db4"] * 3, [n1, n2, n3], pres_l2_norm=True, precision="single", device=torch.device("cuda", 0))
+    assert eng.scheme == "scatter"
+    xs = torch.randn(n3, n2, n1, device="cuda")
+    w = ndwt.nd_dwt_3D("db4", [n1, n2, n3], "pres_l2_norm", 1, "precision", "single")
+    yref = w.dec(xs.permute(2, 1, 0), 3).permute(3, 2, 1, 0)
+    ysh = eng.dec(xs, 3)
+    assert float((ysh - yref).abs().max()) <= 2e-6 * float(yref.abs().max())
+    assert float((eng.rec(ysh) - xs).abs().max()) <= 1e-5
