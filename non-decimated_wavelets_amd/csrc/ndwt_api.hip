@@ -226,7 +226,7 @@ void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int
     (void)Lp;
     *TX = 64;
     *TY = f64 ? 8 : 16;
-    if (!f64 && inverse && variant == 1 && Lp == 8) *TY = Fused3Tile<float, true, 1>::TY;
+    if (!f64 && inverse && variant == 1 && Lp == 8) *TY = Fused3Tile<float, true, 1>::TY;   // tall-tile experiment
 }
 }  // namespace ndwt
 

@@ -55,10 +55,26 @@ template <class K> int launch_fused3(const typename K::Args& a, const FusedTapsD
         default: return -1;                    \
     }
 
-// float: all variants for db4 experiments; others: variant 0
+// Default (variant 0): analysis = Fwd3; synthesis = lane-shift kernel Inv3S for float tap lengths <= 8 (db1..db4),
+// LDS kernel Inv3 otherwise.  Variants 1..3 are A/B alternatives for db4 (NDWT_VARIANT_FWD / NDWT_VARIANT_INV).
 #define NDWT_FUSED_SWITCH(KIND, KINDV, INV, T)                            \
     if (variant == 1 && t.Lp == 8) { switch (t.Lp) { NDWT_FUSED_CASE(KINDV, INV, T, 8, 1) } }  \
     if (variant == 2 && t.Lp == 8) { switch (t.Lp) { NDWT_FUSED_CASE(KINDV, INV, T, 8, 2) } }  \
+    if (variant == 3 && t.Lp == 8) { switch (t.Lp) { NDWT_FUSED_CASE(KIND, INV, T, 8, 3) } }   \
     NDWT_FUSED_SWITCH_V(KIND, INV, T, 0)
+
+// float synthesis: short filters take the lane-shift kernel by default
+#define NDWT_FUSED_SWITCH_INV_F32(T)                                      \
+    if (variant == 1 && t.Lp == 8) { switch (t.Lp) { NDWT_FUSED_CASE(Inv3S, true, T, 8, 1) } }  \
+    if (variant == 3 && t.Lp == 8) { switch (t.Lp) { NDWT_FUSED_CASE(Inv3, true, T, 8, 3) } }   \
+    switch (t.Lp) {                                                       \
+        NDWT_FUSED_CASE(Inv3S, true, T, 2, 2)                             \
+        NDWT_FUSED_CASE(Inv3S, true, T, 4, 2)                             \
+        NDWT_FUSED_CASE(Inv3S, true, T, 6, 2)                             \
+        NDWT_FUSED_CASE(Inv3S, true, T, 8, 2)                             \
+        NDWT_FUSED_CASE(Inv3, true, T, 10, 0)                             \
+        NDWT_FUSED_CASE(Inv3, true, T, 12, 0)                             \
+        default: return -1;                                               \
+    }
 
 }  // namespace ndwt

@@ -4,16 +4,18 @@ namespace ndwt {
 // TX x TY output tile per workgroup of NT threads; RY = output rows per y-stage item; WPE = waves per SIMD the
 // register budget is sized for (amdgpu_waves_per_eu).  V selects a variant (NDWT_VARIANT / ndwt_plan_set_variant):
 // every variant computes the same values, they differ in occupancy and instruction mix only.
-constexpr int kFused3Variants = 3;
+constexpr int kFused3Variants = 4;
 template <typename T, bool INVERSE, int V> struct Fused3Tile;
 // float, analysis
 template <> struct Fused3Tile<float, false, 0> { static constexpr int TX = 64, TY = 16, NT = 256, RY = 4, WPE = 3; };
 template <> struct Fused3Tile<float, false, 1> { static constexpr int TX = 64, TY = 16, NT = 512, RY = 4, WPE = 4; };
 template <> struct Fused3Tile<float, false, 2> { static constexpr int TX = 64, TY = 16, NT = 512, RY = 4, WPE = 4; };
+template <> struct Fused3Tile<float, false, 3> { static constexpr int TX = 64, TY = 16, NT = 256, RY = 4, WPE = 3; };
 // float, synthesis
 template <> struct Fused3Tile<float, true, 0>  { static constexpr int TX = 64, TY = 16, NT = 256, RY = 2, WPE = 2; };
 template <> struct Fused3Tile<float, true, 1>  { static constexpr int TX = 64, TY = 32, NT = 1024, RY = 1, WPE = 4; };  // lane-shift kernel (Inv3S), tall tile
-template <> struct Fused3Tile<float, true, 2>  { static constexpr int TX = 64, TY = 16, NT = 256, RY = 2, WPE = 3; };   // lane-shift kernel (Inv3S)
+template <> struct Fused3Tile<float, true, 2>  { static constexpr int TX = 64, TY = 16, NT = 256, RY = 2, WPE = 3; };   // lane-shift kernel (Inv3S): default for tap lengths <= 8
+template <> struct Fused3Tile<float, true, 3>  { static constexpr int TX = 64, TY = 16, NT = 256, RY = 2, WPE = 2; };   // LDS kernel (Inv3), for A/B runs
 // double
 template <int V> struct Fused3Tile<double, false, V> { static constexpr int TX = 64, TY = 8, NT = 256, RY = 4, WPE = 2; };
 template <int V> struct Fused3Tile<double, true, V>  { static constexpr int TX = 64, TY = 8, NT = 256, RY = 4, WPE = 2; };

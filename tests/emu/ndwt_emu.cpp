@@ -100,8 +100,11 @@ int emu3(int inverse, int Lp, int vec4, const T* in, T* out, int n1, int n2, int
     typedef ndwt::Fused3Tile<T, true, 0> PI;
     typedef ndwt::Fused3Tile<T, false, 1> PF1;
     typedef ndwt::Fused3Tile<T, true, 1> PI1;
+    typedef ndwt::Fused3Tile<T, true, 2> PI2;   // float: the default lane-shift synthesis configuration
     ndwt::fused3_geometry(a, PF::TX, PF::TY, Lp, 2048, zchunk);
     if (variant == 1 && inverse) ndwt::fused3_geometry(a, PI1::TX, PI1::TY, Lp, 2048, zchunk);
+    if (variant == 3 && inverse)
+        return dispatch<T, ndwt::Inv3S, PI2::TX, PI2::TY, PI2::NT, PI2::RY, false>(Lp, vec4, a, lo, hi);
     if (variant == 1)
         return inverse ? dispatch<T, ndwt::Inv3S, PI1::TX, PI1::TY, PI1::NT, PI1::RY, false>(Lp, vec4, a, lo, hi)
                        : dispatch<T, ndwt::Fwd3, PF1::TX, PF1::TY, PF1::NT, PF1::RY, false>(Lp, vec4, a, lo, hi);

@@ -89,7 +89,8 @@ def test_emulated_fused3_synthesis(emu, sizes, wn, vec4, zchunk, small, l2):
     want = orc.spatial_level_rec(c, filt, l2)
     for dtype, tol in ((np.float64, 1e-13), (np.float32, 2e-6)):
         # variants 1 (production tile, float) and 2 (small tile, every tap length) are the lane-shift synthesis kernel
-        for variant in ((0, 1) if not small and dtype == np.float32 else (0, 2) if small else (0,)):
+        # 3: the library's default float synthesis configuration (lane-shift kernel, 64x16 tile, 256 threads)
+        for variant in ((0, 1, 3) if not small and dtype == np.float32 else (0, 2) if small else (0,)):
             got = _run(emu, c, wn, l2, True, dtype, vec4, zchunk, small, variant=variant)
             assert np.isfinite(got).all()
             assert np.abs(got - want).max() <= tol * max(np.abs(want).max(), 1.0)
