@@ -200,10 +200,23 @@ static bool fused3_eligible(const ndwt_plan* p, long long stride, int* Lp_out) {
     return true;
 }
 
+static bool fused2_eligible(const ndwt_plan* p, long long stride, int* Lp_out) {
+    if (p->path != NDWT_PATH_AUTO || p->complexity != NDWT_REAL || stride != 1 || p->ndim != 2) return false;
+    int Lp = p->filt[0].len > p->filt[1].len ? p->filt[0].len : p->filt[1].len;
+    if (Lp > 12) return false;
+    if (p->dims[0] >= (1LL << 30) || p->dims[1] >= (1LL << 30)) return false;
+    *Lp_out = Lp;
+    return true;
+}
+
 static FusedTapsD fused_taps(const ndwt_plan* p, int Lp, bool synthesis) {
     FusedTapsD t;
     t.Lp = Lp;
     for (int a = 0; a < 3; ++a) {
+        if (a >= p->ndim) {
+            for (int j = 0; j < kMaxTaps; ++j) t.lo[a][j] = t.hi[a][j] = 0.0;
+            continue;
+        }
         const AxisFilter& f = p->filt[a];
         pad_taps(synthesis ? f.syn_lo : f.ana_lo, f.len, Lp, t.lo[a]);
         pad_taps(synthesis ? f.syn_hi : f.ana_hi, f.len, Lp, t.hi[a]);
@@ -263,6 +276,48 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     return NDWT_OK;
 }
 
+namespace ndwt {
+int fused2_tile_width(bool inverse, int Lp) {
+    const int LH = inverse ? Lp / 2 : Lp / 2 - 1, RH = inverse ? Lp / 2 - 1 : Lp / 2;
+    return 4 * (64 - (LH + 3) / 4 - (RH + 3) / 4);
+}
+}  // namespace ndwt
+
+template <typename T> static int launch2(bool inverse, const Fused2Args<T>& a, int Lp, bool vec4, const void* td, hipStream_t s);
+template <> int launch2<float>(bool inverse, const Fused2Args<float>& a, int Lp, bool vec4, const void* td, hipStream_t s) {
+    return inverse ? launch_inv2_f32(a, Lp, vec4, td, s) : launch_fwd2_f32(a, Lp, vec4, td, s);
+}
+template <> int launch2<double>(bool inverse, const Fused2Args<double>& a, int Lp, bool vec4, const void* td, hipStream_t s) {
+    return inverse ? launch_inv2_f64(a, Lp, vec4, td, s) : launch_fwd2_f64(a, Lp, vec4, td, s);
+}
+
+// one fused 2-D launch; n2 = output rows; y_wrap=false: inputs carry the y halo (slab mode)
+template <typename T>
+static int fused2_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* in, T* const* out, long long n2, long long in_bstride,
+                      long long out_bstride, bool y_wrap, hipStream_t s) {
+    Fused2Args<T> a;
+    memset(&a, 0, sizeof a);
+    a.n1 = (int)p->dims[0];
+    a.n2 = (int)n2;
+    a.nbatch = 1;
+    a.in_bstride = in_bstride;
+    a.out_bstride = out_bstride;
+    a.y_wrap = y_wrap ? 1 : 0;
+    bool vec4 = (a.n1 % 4 == 0);
+    const int nin = inverse ? 4 : 1, nout = inverse ? 1 : 4;
+    for (int b = 0; b < nin; ++b) { a.in[b] = in[b]; vec4 = vec4 && aligned_vec4<T>(in[b]); }
+    for (int b = 0; b < nout; ++b) { a.out[b] = out[b]; vec4 = vec4 && aligned_vec4<T>(out[b]); }
+    fused2_geometry(a, fused2_tile_width(inverse, Lp), Lp, p->target_blocks * 2, p->force_zchunk);
+    const void* td = p->taps_dev[inverse ? 1 : 0];
+    if (!td) return fail(NDWT_ERR_UNSUPPORTED, "plan has no device tap table");
+    prof_begin(p, inverse ? NDWT_KERNEL_FUSED_SYNTHESIS : NDWT_KERNEL_FUSED_ANALYSIS, s);
+    int rc = launch2<T>(inverse, a, Lp, vec4, td, s);
+    prof_end(p, s);
+    if (rc == -1) return fail(NDWT_ERR_UNSUPPORTED, "no fused 2-D kernel instantiated for tap length %d", Lp);
+    if (rc != 0) return fail(NDWT_ERR_HIP, "fused 2-D kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return NDWT_OK;
+}
+
 // ------------------------------------------------------------------------------------------ levels
 // analysis of one level: in (vol scalars, + halo planes on the outer axis in slab mode) -> 2^d bands
 template <typename T>
@@ -292,6 +347,10 @@ static int analysis_level(ndwt_plan* p, const T* in, T* const* out, long long st
         rc = fused3_run<T>(p, false, Lp, ins_lo, out, p->dims[2], p->dims[3], vol3, vol3, 1, s);
         if (rc) return rc;
         return fused3_run<T>(p, false, Lp, ins_hi, out + 8, p->dims[2], p->dims[3], vol3, vol3, 1, s);
+    }
+    if (fused2_eligible(p, stride, &Lp) && !(slab && ftop.len != Lp)) {
+        const T* ins[4] = {in};
+        return fused2_run<T>(p, false, Lp, ins, out, p->dims[1], vol_in, p->vol, !slab, s);
     }
     GenericCtx<T> c;
     c.p = p; c.stride = stride; c.slab = slab; c.s = s;
@@ -331,6 +390,10 @@ static int synthesis_level(ndwt_plan* p, const T* const* in, T* out, long long s
         rc = fused3_run<T>(p, true, Lp, in + 8, outs_d, p->dims[2], n_top_in, vol3, vol3, 1, s);
         if (rc) return rc;
         return axis_pass<T>(p, true, 3, p->dims, stride, !slab, a, dd, out, nullptr, s);
+    }
+    if (fused2_eligible(p, stride, &Lp) && !(slab && ftop.len != Lp)) {
+        T* outs[4] = {out};
+        return fused2_run<T>(p, true, Lp, in, outs, p->dims[1], vol_in, p->vol, !slab, s);
     }
     GenericCtx<T> c;
     c.p = p; c.stride = stride; c.slab = slab; c.s = s;
@@ -508,7 +571,7 @@ int ndwt_plan_create(ndwt_plan** plan, int ndim, const int64_t* dims, const char
         }
     }
     int Lp = 0;
-    if (fused3_eligible(p, 1, &Lp)) {
+    if (fused3_eligible(p, 1, &Lp) || fused2_eligible(p, 1, &Lp)) {
         for (int inv = 0; inv < 2; ++inv) {
             FusedTapsD t = fused_taps(p, Lp, inv != 0);
             std::vector<char> host((size_t)6 * Lp * p->esize);
@@ -596,6 +659,7 @@ int ndwt_plan_describe(const ndwt_plan* p, char* buf, int buflen) {
     int Lp = 0;
     const char* s = "axis";
     if (fused3_eligible(p, 1, &Lp)) s = p->ndim == 3 ? "fused3d" : "axis+fused3d";
+    else if (fused2_eligible(p, 1, &Lp)) s = "fused2d";
     snprintf(buf, (size_t)buflen, "%s", s);
     return NDWT_OK;
 }

@@ -915,4 +915,270 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
     }
 };
 
+// ------------------------------------------------------------------------------------------------
+// Fused 2-D level, register-only.  Axis 0 = x (contiguous, n1), axis 1 = y (n2, marched).  One WAVE is one tile:
+// lane l owns 4 consecutive x (64 lanes = 256 columns, GL+GR of them halo groups), the y filter runs on a rotating
+// register window while the wave marches down a chunk of rows, and the x filter takes its neighbours from the
+// adjacent lanes (DPP wave shifts).  No LDS, no barriers; 1 read -> 4 writes (analysis) / 4 reads -> 1 write.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct Fused2Args {
+    const T* in[4];        // analysis: in[0]; synthesis: the 4 bands
+    T* out[4];             // analysis: the 4 bands; synthesis: out[0]
+    int n1, n2;
+    int nbatch;
+    long long in_bstride, out_bstride;
+    int ychunk;            // output rows per wave
+    int ntx, nyc;          // wave tiles along x, chunks along y
+    int y_wrap;            // 1: periodic in y; 0: inputs start `left` rows before local row 0 (slab mode)
+    int dbg;
+};
+
+struct Tile2Coord {
+    int x0, ybeg, yend, batch;
+};
+template <typename T> NDWT_DEV Tile2Coord decode_tile2(const Fused2Args<T>& a, int bid, int WX) {
+    Tile2Coord tc;
+    int tx = bid % a.ntx;
+    bid /= a.ntx;
+    int yc = bid % a.nyc;
+    tc.batch = bid / a.nyc;
+    tc.x0 = tx * WX;
+    tc.ybeg = yc * a.ychunk;
+    tc.yend = tc.ybeg + a.ychunk < a.n2 ? tc.ybeg + a.ychunk : a.n2;
+    return tc;
+}
+
+template <typename T, int L_, bool VEC4_, int WPE_ = 4> struct Fwd2S {
+    static constexpr int L = L_, NT = 64, WPE = WPE_;
+    static constexpr bool VEC4 = VEC4_;
+    static constexpr int NE = VEC4 ? 1 : 4;
+    static constexpr int LH = L / 2 - 1, RH = L / 2;
+    static constexpr int GL = (LH + 3) / 4, GR = (RH + 3) / 4;
+    static constexpr int WX = 4 * (64 - GL - GR);        // output columns per wave
+    static constexpr int XV = 4 * (1 + GL + GR);
+    typedef typename VecT<T>::v2 v2;
+    typedef typename VecT<T>::v4 v4;
+    typedef Taps3<T, L> Taps;                            // axes 0 (x) and 1 (y) are used
+    typedef Fused2Args<T> Args;
+    struct Shared { int unused; };
+    struct State {
+        v4 win[L];         // raw rows, rotating
+        v4 nxt;            // prefetched row
+        v2 yz[4];          // (lo2, hi2) of this lane's 4 x, read by the neighbouring lanes
+        int off[NE];
+    };
+
+    static NDWT_DEV void setup(State& st, const Args& a, const Tile2Coord& tc, int tid) {
+        int xb = tc.x0 - 4 * GL + 4 * tid;
+        NDWT_SFOR(e, NE)
+            st.off[e] = modn(xb + e, a.n1);
+        NDWT_SEND
+    }
+    static NDWT_DEV void load_row(State& st, const Args& a, const T* inb, int yraw) {
+        long long ym = a.y_wrap ? (long long)modn(yraw, a.n2) : (long long)(yraw + LH);
+        const T* p = inb + ym * a.n1;
+        if constexpr (VEC4) {
+            st.nxt = *reinterpret_cast<const v4*>(p + st.off[0]);
+        } else {
+            NDWT_SFOR(e, NE)
+                st.nxt[e] = p[st.off[e]];
+            NDWT_SEND
+        }
+    }
+    template <int R> static NDWT_DEV void ystage(State& st, const Taps& tp) {
+        st.win[(R + L - 1) % L] = st.nxt;
+        v2 acc[4];
+        acc[0] = acc[1] = acc[2] = acc[3] = (v2)(T(0));
+        NDWT_SFOR(j, L)
+            v4 w = st.win[(R + j) % L];
+            v2 t = {tp.lo[1][j], tp.hi[1][j]};
+            acc[0] += t * w[0]; acc[1] += t * w[1]; acc[2] += t * w[2]; acc[3] += t * w[3];
+        NDWT_SEND
+        st.yz[0] = acc[0]; st.yz[1] = acc[1]; st.yz[2] = acc[2]; st.yz[3] = acc[3];
+    }
+    template <int R> static NDWT_DEV void ydispatch(int r, State& st, const Taps& tp) {
+        if constexpr (R < L) {
+            if (r == R) ystage<R>(st, tp);
+            else ydispatch<R + 1>(r, st, tp);
+        }
+    }
+    static NDWT_DEV void prologue(State& st, const Args& a, const T* inb, int ybeg) {
+        NDWT_SFOR(j, L - 1)
+            load_row(st, a, inb, ybeg - LH + j);
+            st.win[j] = st.nxt;
+        NDWT_SEND
+    }
+    // every lane executes the shifts; stores are predicated
+    template <class Exec> static NDWT_DEV void xstage(Exec& ex, State& st, const Taps& tp, const Args& a, const Tile2Coord& tc,
+                                                      long long obase, int y, int tid) {
+        v2 xlo[4], xhi[4];
+        NDWT_SFOR(e, 4)
+            xlo[e] = (v2)(T(0));
+            xhi[e] = (v2)(T(0));
+        NDWT_SEND
+        NDWT_SFOR(i, XV)
+            constexpr int D = i / 4 - GL;
+            constexpr int c = i % 4;
+            constexpr int jlo = i - (4 * GL + 3 - LH), jhi = i - (4 * GL - LH);
+            if constexpr (jhi >= 0 && jlo < L) {
+                v2 v = {NDWT_LANE_SHIFT(ex, tid, D, s.yz[c].x), NDWT_LANE_SHIFT(ex, tid, D, s.yz[c].y)};
+                NDWT_SFOR(e, 4)
+                    constexpr int j = i - (4 * GL + e - LH);
+                    if constexpr (j >= 0 && j < L) {
+                        xlo[e] += tp.lo[0][j] * v;
+                        xhi[e] += tp.hi[0][j] * v;
+                    }
+                NDWT_SEND
+            }
+        NDWT_SEND
+        int gx = tc.x0 + 4 * (tid - GL);
+        if (tid < GL || tid >= 64 - GR || gx >= a.n1) return;
+        long long off = obase + (long long)y * a.n1 + gx;
+        v4 o0 = {xlo[0].x, xlo[1].x, xlo[2].x, xlo[3].x}, o1 = {xhi[0].x, xhi[1].x, xhi[2].x, xhi[3].x};
+        v4 o2 = {xlo[0].y, xlo[1].y, xlo[2].y, xlo[3].y}, o3 = {xhi[0].y, xhi[1].y, xhi[2].y, xhi[3].y};
+        if constexpr (VEC4) {
+            *reinterpret_cast<v4*>(a.out[0] + off) = o0;
+            *reinterpret_cast<v4*>(a.out[1] + off) = o1;
+            *reinterpret_cast<v4*>(a.out[2] + off) = o2;
+            *reinterpret_cast<v4*>(a.out[3] + off) = o3;
+        } else {
+            NDWT_SFOR(e, 4)
+                if (gx + e < a.n1) { a.out[0][off + e] = o0[e]; a.out[1][off + e] = o1[e]; a.out[2][off + e] = o2[e]; a.out[3][off + e] = o3[e]; }
+            NDWT_SEND
+        }
+    }
+
+    template <class Exec> static NDWT_DEV void block(Exec& ex, Shared&, const Args& a, const Taps& tp, int bid) {
+        const Tile2Coord tc = decode_tile2(a, bid, WX);
+        const T* inb = a.in[0] + (long long)tc.batch * a.in_bstride;
+        const long long obase = (long long)tc.batch * a.out_bstride;
+        ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+            setup(st, a, tc, tid);
+            prologue(st, a, inb, tc.ybeg);
+            load_row(st, a, inb, tc.ybeg + RH);
+        });
+        const int nsteps = tc.yend - tc.ybeg;
+        for (int s = 0; s < nsteps; ++s) {
+            const int y = tc.ybeg + s;
+            ex.each([&](int, State& st) __attribute__((always_inline)) {
+                ydispatch<0>(s % L, st, tp);
+                if (s + 1 < nsteps) load_row(st, a, inb, y + 1 + RH);
+            });
+            ex.each([&](int tid, State& st) __attribute__((always_inline)) { xstage(ex, st, tp, a, tc, obase, y, tid); });
+        }
+    }
+};
+
+template <typename T, int L_, bool VEC4_, int WPE_ = 4> struct Inv2S {
+    static constexpr int L = L_, NT = 64, WPE = WPE_;
+    static constexpr bool VEC4 = VEC4_;
+    static constexpr int NE = VEC4 ? 1 : 4;
+    static constexpr int LH = L / 2, RH = L / 2 - 1;
+    static constexpr int GL = (LH + 3) / 4, GR = (RH + 3) / 4;
+    static constexpr int WX = 4 * (64 - GL - GR);
+    static constexpr int XV = 4 * (1 + GL + GR);
+    typedef typename VecT<T>::v2 v2;
+    typedef typename VecT<T>::v4 v4;
+    typedef Taps3<T, L> Taps;
+    typedef Fused2Args<T> Args;
+    struct Shared { int unused; };
+    struct State {
+        T yacc[L][4];      // y-synthesis in scatter form: partial sums of the next L output rows (4 x each)
+        v4 raw[4];         // 4 x of every band of the newest row
+        int off[NE];
+    };
+    static NDWT_DEV void setup(State& st, const Args& a, const Tile2Coord& tc, int tid) {
+        int xb = tc.x0 - 4 * GL + 4 * tid;
+        NDWT_SFOR(e, NE)
+            st.off[e] = modn(xb + e, a.n1);
+        NDWT_SEND
+    }
+    static NDWT_DEV void load_row(State& st, const Args& a, long long ibase, int yraw) {
+        long long ym = a.y_wrap ? (long long)modn(yraw, a.n2) : (long long)(yraw + LH);
+        NDWT_SFOR(b, 4)
+            const T* p = a.in[b] + ibase + ym * a.n1;
+            if constexpr (VEC4) {
+                st.raw[b] = *reinterpret_cast<const v4*>(p + st.off[0]);
+            } else {
+                NDWT_SFOR(e, NE)
+                    st.raw[b][e] = p[st.off[e]];
+                NDWT_SEND
+            }
+        NDWT_SEND
+    }
+    // x-synthesis of the newest row via lane shifts, then y-synthesis (scatter); rotation R as in Inv3S
+    template <int R, class Exec>
+    static NDWT_DEV void step(Exec& ex, State& st, const Taps& tp, const Args& a, const Tile2Coord& tc, long long obase, int y,
+                              bool emit, int tid) {
+        v2 P[4];           // (a, d) of the y-synthesis = x-synthesis of (y-bit 0, y-bit 1)
+        NDWT_SFOR(e, 4)
+            P[e] = (v2)(T(0));
+        NDWT_SEND
+        NDWT_SFOR(i, XV)
+            constexpr int D = i / 4 - GL;
+            constexpr int c = i % 4;
+            constexpr int jlo = i - (4 * GL + 3 - LH), jhi = i - (4 * GL - LH);
+            if constexpr (jhi >= 0 && jlo < L) {
+                v2 wa = {NDWT_LANE_SHIFT(ex, tid, D, s.raw[0][c]), NDWT_LANE_SHIFT(ex, tid, D, s.raw[2][c])};   // x-bit 0
+                v2 wd = {NDWT_LANE_SHIFT(ex, tid, D, s.raw[1][c]), NDWT_LANE_SHIFT(ex, tid, D, s.raw[3][c])};   // x-bit 1
+                NDWT_SFOR(e, 4)
+                    constexpr int j = i - (4 * GL + e - LH);
+                    if constexpr (j >= 0 && j < L) {
+                        P[e] += tp.lo[0][j] * wa;
+                        P[e] += tp.hi[0][j] * wd;
+                    }
+                NDWT_SEND
+            }
+        NDWT_SEND
+        NDWT_SFOR(j, L)
+            constexpr int slot = ((R - 1 - j) % L + L) % L;
+            NDWT_SFOR(e, 4)
+                const T c = tp.lo[1][j] * P[e].x + tp.hi[1][j] * P[e].y;
+                if constexpr (j == 0) st.yacc[slot][e] = c;
+                else st.yacc[slot][e] += c;
+            NDWT_SEND
+        NDWT_SEND
+        if (!emit) return;
+        constexpr int done = ((R - L) % L + L) % L;
+        int gx = tc.x0 + 4 * (tid - GL);
+        if (tid < GL || tid >= 64 - GR || gx >= a.n1) return;
+        long long off = obase + (long long)y * a.n1 + gx;
+        if constexpr (VEC4) {
+            *reinterpret_cast<v4*>(a.out[0] + off) = v4{st.yacc[done][0], st.yacc[done][1], st.yacc[done][2], st.yacc[done][3]};
+        } else {
+            NDWT_SFOR(e, 4)
+                if (gx + e < a.n1) a.out[0][off + e] = st.yacc[done][e];
+            NDWT_SEND
+        }
+    }
+    template <int R, class Exec>
+    static NDWT_DEV void dispatch(int r, Exec& ex, State& st, const Taps& tp, const Args& a, const Tile2Coord& tc, long long obase,
+                                  int y, bool emit, int tid) {
+        if constexpr (R < L) {
+            if (r == R) step<R>(ex, st, tp, a, tc, obase, y, emit, tid);
+            else dispatch<R + 1>(r, ex, st, tp, a, tc, obase, y, emit, tid);
+        }
+    }
+    template <class Exec> static NDWT_DEV void block(Exec& ex, Shared&, const Args& a, const Taps& tp, int bid) {
+        const Tile2Coord tc = decode_tile2(a, bid, WX);
+        const long long ibase = (long long)tc.batch * a.in_bstride;
+        const long long obase = (long long)tc.batch * a.out_bstride;
+        const int nsteps = tc.yend - tc.ybeg;
+        const int nrows = nsteps + L - 1;
+        ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+            setup(st, a, tc, tid);
+            load_row(st, a, ibase, tc.ybeg - LH);
+        });
+        for (int p = 0; p < nrows; ++p) {
+            const int s = p - (L - 1);
+            ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+                dispatch<0>((p + 1) % L, ex, st, tp, a, tc, obase, tc.ybeg + s, s >= 0, tid);
+            });
+            ex.each([&](int, State& st) __attribute__((always_inline)) {
+                if (p + 1 < nrows) load_row(st, a, ibase, tc.ybeg - LH + p + 1);
+            });
+        }
+    }
+};
+
 }  // namespace ndwt

@@ -23,4 +23,11 @@ int launch_inv3_f32(const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, 
 int launch_fwd3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4, int variant, const void* taps_dev, hipStream_t s);
 int launch_inv3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4, int variant, const void* taps_dev, hipStream_t s);
 
+// fused 2-D kernels (register-only, one wave per tile)
+int fused2_tile_width(bool inverse, int Lp);
+int launch_fwd2_f32(const Fused2Args<float>& a, int Lp, bool vec4, const void* taps_dev, hipStream_t s);
+int launch_inv2_f32(const Fused2Args<float>& a, int Lp, bool vec4, const void* taps_dev, hipStream_t s);
+int launch_fwd2_f64(const Fused2Args<double>& a, int Lp, bool vec4, const void* taps_dev, hipStream_t s);
+int launch_inv2_f64(const Fused2Args<double>& a, int Lp, bool vec4, const void* taps_dev, hipStream_t s);
+
 }  // namespace ndwt

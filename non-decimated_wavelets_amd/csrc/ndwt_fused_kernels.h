@@ -34,6 +34,26 @@ template <class K> int launch_fused3(const typename K::Args& a, const FusedTapsD
     return (int)hipGetLastError();
 }
 
+template <class K> int launch_fused2(const typename K::Args& a, const void* taps_dev, hipStream_t s) {
+    const int nblocks = a.ntx * a.nyc * a.nbatch;
+    hipLaunchKernelGGL(fused3_kernel<K>, dim3(nblocks), dim3(K::NT), 0, s, a, (const typename K::Taps*)taps_dev);
+    return (int)hipGetLastError();
+}
+
+#define NDWT_FUSED2_CASE(KIND, T, LL)                                                        \
+    case LL:                                                                                 \
+        return vec4 ? launch_fused2<KIND<T, LL, true, (sizeof(T) == 8 ? 2 : 4)>>(a, taps_dev, s) : launch_fused2<KIND<T, LL, false, (sizeof(T) == 8 ? 2 : 4)>>(a, taps_dev, s);
+#define NDWT_FUSED2_SWITCH(KIND, T)   \
+    switch (Lp) {                     \
+        NDWT_FUSED2_CASE(KIND, T, 2)  \
+        NDWT_FUSED2_CASE(KIND, T, 4)  \
+        NDWT_FUSED2_CASE(KIND, T, 6)  \
+        NDWT_FUSED2_CASE(KIND, T, 8)  \
+        NDWT_FUSED2_CASE(KIND, T, 10) \
+        NDWT_FUSED2_CASE(KIND, T, 12) \
+        default: return -1;           \
+    }
+
 // dispatch on variant, padded tap length and vector path
 #define NDWT_FUSED_K(KIND, INV, T, LL, V, VEC)                                                               \
     KIND<T, LL, Fused3Tile<T, INV, V>::TX, Fused3Tile<T, INV, V>::TY, Fused3Tile<T, INV, V>::NT,             \

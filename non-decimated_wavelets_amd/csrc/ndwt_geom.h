@@ -32,4 +32,21 @@ inline bool fused3_fits(long long n1, long long n2, long long n3, long long nbat
     return n1 * n2 < (1LL << 31) && n3 < (1LL << 30) && nbatch < (1LL << 20) && n1 >= 1 && n2 >= 1 && n3 >= 1;
 }
 
+// fused 2-D kernels: one wave (64 lanes x 4 columns, minus halo groups) marches `ychunk` rows
+template <typename T>
+inline void fused2_geometry(Fused2Args<T>& a, int WX, int Lp, int target_waves = 4096, int force_ychunk = 0) {
+    a.ntx = (a.n1 + WX - 1) / WX;
+    long long per_chunk = (long long)a.ntx * a.nbatch;
+    int want = (int)((target_waves + per_chunk - 1) / per_chunk);
+    if (want < 1) want = 1;
+    int yc = (a.n2 + want - 1) / want;
+    int min_chunk = 4 * (Lp - 1);
+    if (min_chunk < 8) min_chunk = 8;
+    if (yc < min_chunk) yc = min_chunk;
+    if (yc > a.n2) yc = a.n2;
+    if (force_ychunk > 0) yc = force_ychunk < a.n2 ? force_ychunk : a.n2;
+    a.ychunk = yc;
+    a.nyc = (a.n2 + yc - 1) / yc;
+}
+
 }  // namespace ndwt

@@ -112,9 +112,66 @@ int emu3(int inverse, int Lp, int vec4, const T* in, T* out, int n1, int n2, int
                    : dispatch<T, ndwt::Fwd3, PF::TX, PF::TY, PF::NT, PF::RY, false>(Lp, vec4, a, lo, hi);
 }
 
+template <class K, typename T> int run2(ndwt::Fused2Args<T>& a, const double* lo, const double* hi) {
+    typename K::Taps tp;
+    for (int ax = 0; ax < 3; ++ax)
+        for (int j = 0; j < K::L; ++j) {
+            tp.lo[ax][j] = (T)lo[ax * ndwt::kMaxTaps + j];
+            tp.hi[ax][j] = (T)hi[ax * ndwt::kMaxTaps + j];
+        }
+    const int nblocks = a.ntx * a.nyc * a.nbatch;
+    for (int b = 0; b < nblocks; ++b) {
+        typename K::Shared sh;
+        EmuExec<typename K::State, K::NT> ex;
+        K::block(ex, sh, a, tp, b);
+    }
+    return 0;
+}
+
+template <typename T>
+int emu2(int inverse, int Lp, int vec4, const T* in, T* out, int n1, int n2, int ychunk, const double* lo, const double* hi,
+         int y_wrap) {
+    ndwt::Fused2Args<T> a;
+    std::memset(&a, 0, sizeof(a));
+    a.n1 = n1; a.n2 = n2; a.nbatch = 1;
+    const long long vol = (long long)n1 * n2;
+    const long long vol_in = y_wrap ? vol : (long long)n1 * (n2 + Lp - 1);
+    a.y_wrap = y_wrap;
+    a.in_bstride = vol_in; a.out_bstride = vol;
+    if (!inverse) {
+        a.in[0] = in;
+        for (int b = 0; b < 4; ++b) a.out[b] = out + b * vol;
+    } else {
+        for (int b = 0; b < 4; ++b) a.in[b] = in + b * vol_in;
+        a.out[0] = out;
+    }
+#define CASE2(LL)                                                                                                       \
+    case LL:                                                                                                            \
+        if (inverse) {                                                                                                  \
+            ndwt::fused2_geometry(a, ndwt::Inv2S<T, LL, true>::WX, Lp, 64, ychunk);                                      \
+            return vec4 ? run2<ndwt::Inv2S<T, LL, true>, T>(a, lo, hi) : run2<ndwt::Inv2S<T, LL, false>, T>(a, lo, hi); \
+        } else {                                                                                                        \
+            ndwt::fused2_geometry(a, ndwt::Fwd2S<T, LL, true>::WX, Lp, 64, ychunk);                                      \
+            return vec4 ? run2<ndwt::Fwd2S<T, LL, true>, T>(a, lo, hi) : run2<ndwt::Fwd2S<T, LL, false>, T>(a, lo, hi); \
+        }
+    switch (Lp) {
+        CASE2(2) CASE2(4) CASE2(6) CASE2(8) CASE2(10) CASE2(12)
+        default: return -1;
+    }
+#undef CASE2
+}
+
 }  // namespace
 
 extern "C" {
+int ndwt_emu2_f32(int inverse, int Lp, int vec4, const float* in, float* out, int n1, int n2, int ychunk, const double* lo,
+                  const double* hi, int y_wrap) {
+    return emu2<float>(inverse, Lp, vec4, in, out, n1, n2, ychunk, lo, hi, y_wrap);
+}
+int ndwt_emu2_f64(int inverse, int Lp, int vec4, const double* in, double* out, int n1, int n2, int ychunk, const double* lo,
+                  const double* hi, int y_wrap) {
+    return emu2<double>(inverse, Lp, vec4, in, out, n1, n2, ychunk, lo, hi, y_wrap);
+}
 // in/out: band-planar, batch inside band: [band][batch][n3(+halo)][n2][n1]; lo/hi: [3][20] padded kernel-form taps
 int ndwt_emu3_f32(int inverse, int Lp, int vec4, const float* in, float* out, int n1, int n2, int n3, int nbatch,
                   int zchunk, const double* lo, const double* hi, int z_wrap, int small_tile, int variant) {

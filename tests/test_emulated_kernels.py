@@ -94,3 +94,55 @@ def test_emulated_fused3_synthesis(emu, sizes, wn, vec4, zchunk, small, l2):
             got = _run(emu, c, wn, l2, True, dtype, vec4, zchunk, small, variant=variant)
             assert np.isfinite(got).all()
             assert np.abs(got - want).max() <= tol * max(np.abs(want).max(), 1.0)
+
+
+def _run2(emu, arr, wnames, l2, inverse, dtype, vec4, ychunk):
+    Ls = [len(orc.wave_filters(w)[0]) for w in wnames]
+    Lp = max(Ls)
+    lo = np.zeros((3, 20))
+    hi = np.zeros((3, 20))
+    for ax in range(2):
+        t = kernel_taps(wnames[ax], l2, Lp)
+        lo[ax, :Lp] = t["syn_lo" if inverse else "ana_lo"]
+        hi[ax, :Lp] = t["syn_hi" if inverse else "ana_hi"]
+    src = to_kernel_order(arr).astype(dtype)
+    if inverse:
+        n2, n1 = src.shape[1:]
+        out = np.full((n2, n1), np.nan, dtype=dtype)
+    else:
+        n2, n1 = src.shape
+        out = np.full((4, n2, n1), np.nan, dtype=dtype)
+    fn = emu.ndwt_emu2_f32 if dtype == np.float32 else emu.ndwt_emu2_f64
+    fn.restype = ctypes.c_int
+    rc = fn(int(inverse), Lp, int(vec4), src.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), n1, n2, ychunk,
+            lo.ctypes.data_as(ctypes.c_void_p), hi.ctypes.data_as(ctypes.c_void_p), 1)
+    assert rc == 0
+    return np.transpose(out)
+
+
+CASES2 = [
+    # sizes (n1,n2), wavelets, vec4, ychunk
+    ((40, 13), ("db1", "db3"), True, 0),
+    ((255, 9), ("db4", "db2"), False, 4),      # more than one wave tile along x, odd width
+    ((516, 20), ("db4", "db4"), True, 7),      # three wave tiles, several row chunks
+    ((36, 30), ("db6", "db5"), True, 11),      # two-lane shifts
+    ((30, 12), ("db2", "db6"), False, 0),
+]
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("sizes,wn,vec4,ychunk", CASES2)
+@pytest.mark.parametrize("l2", [0, 1])
+def test_emulated_fused2(emu, sizes, wn, vec4, ychunk, l2):
+    """register-only 2-D kernels (lane-shift x filter): one level against nd_dwt_2D.m:312-337 semantics"""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(sizes)
+    c = rng.standard_normal(tuple(sizes) + (4,))
+    filt = [orc.wave_filters(w) for w in wn]
+    want_y = orc.spatial_level_dec(x, filt, l2)
+    want_r = orc.spatial_level_rec(c, filt, l2)
+    for dtype, tol in ((np.float64, 1e-13), (np.float32, 2e-6)):
+        got = _run2(emu, x, wn, l2, False, dtype, vec4, ychunk)
+        assert np.isfinite(got).all() and np.abs(got - want_y).max() <= tol * np.abs(want_y).max()
+        got = _run2(emu, c, wn, l2, True, dtype, vec4, ychunk)
+        assert np.isfinite(got).all() and np.abs(got - want_r).max() <= tol * max(np.abs(want_r).max(), 1.0)

@@ -303,3 +303,22 @@ def test_copy_free_slab_entry_points_and_sharded_driver_on_one_gpu():
     ysh = eng.dec(xs, 3)
     assert float((ysh - yref).abs().max()) <= 2e-6 * float(yref.abs().max())
     assert float((eng.rec(ysh) - xs).abs().max()) <= 1e-5
+
+
+def test_fused2d_kernels_at_baseline_config2_shape():
+    """BASELINE config 2 (2-D fp32 4096x4096 db4, 3 levels): fused 2-D kernels vs the per-axis kernels + round trip"""
+    torch.manual_seed(2)
+    n1 = n2 = 4096
+    x = torch.randn(n2, n1, device="cuda", dtype=torch.float32).permute(1, 0)
+    w = ndwt.nd_dwt_2D("db4", [n1, n2], "pres_l2_norm", 1, "precision", "single")
+    y = w.dec(x, 3)
+    p = list(w._plans.values())[0]
+    assert p.describe() == "fused2d"
+    assert y.shape == (n1, n2, 10)
+    r = w.rec(y)
+    nx = float(torch.linalg.vector_norm(x.double()))
+    assert float(torch.linalg.vector_norm((r - x).double())) / nx < 1e-6
+    assert abs(float(torch.linalg.vector_norm(y.double())) - nx) < 2e-6 * nx
+    p.set_path(True)
+    yg = w.dec(x, 3)
+    assert float((y - yg).abs().max()) <= 2e-6 * float(yg.abs().max())
