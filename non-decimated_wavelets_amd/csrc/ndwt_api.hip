@@ -76,7 +76,9 @@ struct ndwt_plan {
     size_t tmp_bytes;
     int target_blocks;                 // fused-kernel grid sizing
     int force_zchunk;
+    int zchunk_dir[2];                 // per-direction override of the marched chunk: [0] analysis, [1] synthesis (0 = auto)
     int variant_fwd, variant_inv;      // fused-kernel variants (tuning experiments; same results)
+    int num_cus;
     void* taps_dev[2];                 // device tap tables of the fused kernels: [0] analysis, [1] synthesis (Taps3<T, Lp>)
     // optional per-kernel timing with HIP events on the launch stream (bench.py's roofline figures)
     int profiling;
@@ -239,7 +241,7 @@ void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int
     (void)Lp;
     *TX = 64;
     *TY = f64 ? 8 : 16;
-    if (!f64 && inverse && variant == 1 && Lp == 8) *TY = Fused3Tile<float, true, 1>::TY;   // tall-tile experiment
+    if (!f64 && inverse && !((variant == 2 || variant == 3) && Lp == 8)) *TY = 32;   // float synthesis default: tall tile
 }
 }  // namespace ndwt
 
@@ -264,7 +266,11 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     int TX = 0, TY = 0;
     const int variant = inverse ? p->variant_inv : p->variant_fwd;
     fused3_tile_shape(sizeof(T) == 8, inverse, variant, Lp, &TX, &TY);
-    fused3_geometry(a, TX, TY, Lp, p->target_blocks, p->force_zchunk);
+    const int zc_force = p->zchunk_dir[inverse ? 1 : 0] > 0 ? p->zchunk_dir[inverse ? 1 : 0] : p->force_zchunk;
+    // the 1024-thread synthesis kernel runs one workgroup per CU: aim at one wave of workgroups over the chip
+    const bool tall = TY == 32;
+    const int target = (tall && p->target_blocks == 2048) ? p->num_cus : p->target_blocks;
+    fused3_geometry(a, TX, TY, Lp, target, zc_force);
     FusedTapsD t = fused_taps(p, Lp, inverse);
     const void* td = p->taps_dev[inverse ? 1 : 0];
     if (!td) return fail(NDWT_ERR_UNSUPPORTED, "plan has no device tap table");
@@ -539,6 +545,8 @@ int ndwt_plan_create(ndwt_plan** plan, int ndim, const int64_t* dims, const char
     p->prof = new std::vector<ProfRec>();
     if (const char* v = getenv("NDWT_VARIANT_FWD")) p->variant_fwd = atoi(v);
     if (const char* v = getenv("NDWT_VARIANT_INV")) p->variant_inv = atoi(v);
+    if (const char* v = getenv("NDWT_ZCHUNK_FWD")) p->zchunk_dir[0] = atoi(v);
+    if (const char* v = getenv("NDWT_ZCHUNK_INV")) p->zchunk_dir[1] = atoi(v);
     static const char* ordn[4] = {"First", "Second", "Third", "Fourth"};
     p->vol = p->comp;
     for (int a = 0; a < ndim; ++a) {
@@ -562,6 +570,10 @@ int ndwt_plan_create(ndwt_plan** plan, int ndim, const int64_t* dims, const char
         return fail(NDWT_ERR_NO_DEVICE, "no usable HIP device (requested %d of %d): this engine has no CPU path", device, ndev);
     }
     if (hipSetDevice(device) != hipSuccess) { delete p->prof; delete p; return fail(NDWT_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device); }
+    {
+        hipDeviceProp_t prop;
+        p->num_cus = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
     const int napprox = max_level >= 3 ? 2 : (max_level == 2 ? 1 : 0);
     for (int i = 0; i < napprox; ++i) {
         hipError_t e = hipMalloc(&p->approx[i], (size_t)p->vol * p->esize);

@@ -83,17 +83,18 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
     if (variant == 3 && t.Lp == 8) { switch (t.Lp) { NDWT_FUSED_CASE(KIND, INV, T, 8, 3) } }   \
     NDWT_FUSED_SWITCH_V(KIND, INV, T, 0)
 
-// float synthesis: short filters take the lane-shift kernel by default
+// float synthesis: the lane-shift kernel on a tall 64x32 tile (1024 threads, one workgroup per CU) is the default;
+// variant 2 = the same kernel on 64x16 / 256 threads, variant 3 = the LDS kernel (A/B runs, db4 only)
 #define NDWT_FUSED_SWITCH_INV_F32(T)                                      \
-    if (variant == 1 && t.Lp == 8) { switch (t.Lp) { NDWT_FUSED_CASE(Inv3S, true, T, 8, 1) } }  \
+    if (variant == 2 && t.Lp == 8) { switch (t.Lp) { NDWT_FUSED_CASE(Inv3S, true, T, 8, 2) } }  \
     if (variant == 3 && t.Lp == 8) { switch (t.Lp) { NDWT_FUSED_CASE(Inv3, true, T, 8, 3) } }   \
     switch (t.Lp) {                                                       \
-        NDWT_FUSED_CASE(Inv3S, true, T, 2, 2)                             \
-        NDWT_FUSED_CASE(Inv3S, true, T, 4, 2)                             \
-        NDWT_FUSED_CASE(Inv3S, true, T, 6, 2)                             \
-        NDWT_FUSED_CASE(Inv3S, true, T, 8, 2)                             \
-        NDWT_FUSED_CASE(Inv3, true, T, 10, 0)                             \
-        NDWT_FUSED_CASE(Inv3, true, T, 12, 0)                             \
+        NDWT_FUSED_CASE(Inv3S, true, T, 2, 1)                             \
+        NDWT_FUSED_CASE(Inv3S, true, T, 4, 1)                             \
+        NDWT_FUSED_CASE(Inv3S, true, T, 6, 1)                             \
+        NDWT_FUSED_CASE(Inv3S, true, T, 8, 1)                             \
+        NDWT_FUSED_CASE(Inv3S, true, T, 10, 1)                            \
+        NDWT_FUSED_CASE(Inv3S, true, T, 12, 1)                            \
         default: return -1;                                               \
     }
 

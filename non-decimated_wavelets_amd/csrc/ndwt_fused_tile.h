@@ -13,8 +13,8 @@ template <> struct Fused3Tile<float, false, 2> { static constexpr int TX = 64, T
 template <> struct Fused3Tile<float, false, 3> { static constexpr int TX = 64, TY = 16, NT = 256, RY = 4, WPE = 3; };
 // float, synthesis
 template <> struct Fused3Tile<float, true, 0>  { static constexpr int TX = 64, TY = 16, NT = 256, RY = 2, WPE = 2; };
-template <> struct Fused3Tile<float, true, 1>  { static constexpr int TX = 64, TY = 32, NT = 1024, RY = 1, WPE = 4; };  // lane-shift kernel (Inv3S), tall tile
-template <> struct Fused3Tile<float, true, 2>  { static constexpr int TX = 64, TY = 16, NT = 256, RY = 2, WPE = 3; };   // lane-shift kernel (Inv3S): default for tap lengths <= 8
+template <> struct Fused3Tile<float, true, 1>  { static constexpr int TX = 64, TY = 32, NT = 1024, RY = 1, WPE = 4; };  // lane-shift kernel (Inv3S), tall tile: the float default
+template <> struct Fused3Tile<float, true, 2>  { static constexpr int TX = 64, TY = 16, NT = 256, RY = 2, WPE = 3; };   // lane-shift kernel (Inv3S), 64x16 tile, for A/B runs
 template <> struct Fused3Tile<float, true, 3>  { static constexpr int TX = 64, TY = 16, NT = 256, RY = 2, WPE = 2; };   // LDS kernel (Inv3), for A/B runs
 // double
 template <int V> struct Fused3Tile<double, false, V> { static constexpr int TX = 64, TY = 8, NT = 256, RY = 4, WPE = 2; };
