@@ -242,6 +242,7 @@ void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int
     *TX = 64;
     *TY = f64 ? 8 : 16;
     if (!f64 && inverse && !((variant == 2 || variant == 3) && Lp == 8)) *TY = 32;   // float synthesis default: tall tile
+    if (!f64 && !inverse && variant == 2 && (Lp == 8 || Lp == 12)) *TY = 32;
 }
 }  // namespace ndwt
 
@@ -268,7 +269,7 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     fused3_tile_shape(sizeof(T) == 8, inverse, variant, Lp, &TX, &TY);
     const int zc_force = p->zchunk_dir[inverse ? 1 : 0] > 0 ? p->zchunk_dir[inverse ? 1 : 0] : p->force_zchunk;
     // the 1024-thread synthesis kernel runs one workgroup per CU: aim at one wave of workgroups over the chip
-    const bool tall = TY == 32;
+    const bool tall = TY == 32 && inverse;
     const int target = (tall && p->target_blocks == 2048) ? p->num_cus : p->target_blocks;
     fused3_geometry(a, TX, TY, Lp, target, zc_force);
     FusedTapsD t = fused_taps(p, Lp, inverse);

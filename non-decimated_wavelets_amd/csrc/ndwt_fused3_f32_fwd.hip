@@ -2,6 +2,6 @@
 #include "ndwt_fused_kernels.h"
 namespace ndwt {
 int launch_fwd3_f32(const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, int variant, const void* taps_dev, hipStream_t s) {
-    NDWT_FUSED_SWITCH(Fwd3, Fwd3, false, float)
+    NDWT_FUSED_SWITCH_FWD_F32(float)
 }
 }  // namespace ndwt

@@ -98,4 +98,18 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
         default: return -1;                                               \
     }
 
+// float analysis: 256-thread kernel for tap lengths <= 8, 512 threads (one column per thread) for 10 and 12;
+// variant 2 = tall 64x32 tile with 1024 threads (A/B runs)
+#define NDWT_FUSED_SWITCH_FWD_F32(T)                                      \
+    if (variant == 2) { switch (t.Lp) { NDWT_FUSED_CASE(Fwd3, false, T, 8, 2) NDWT_FUSED_CASE(Fwd3, false, T, 12, 2) } }  \
+    switch (t.Lp) {                                                       \
+        NDWT_FUSED_CASE(Fwd3, false, T, 2, 0)                             \
+        NDWT_FUSED_CASE(Fwd3, false, T, 4, 0)                             \
+        NDWT_FUSED_CASE(Fwd3, false, T, 6, 0)                             \
+        NDWT_FUSED_CASE(Fwd3, false, T, 8, 0)                             \
+        NDWT_FUSED_CASE(Fwd3, false, T, 10, 1)                            \
+        NDWT_FUSED_CASE(Fwd3, false, T, 12, 1)                            \
+        default: return -1;                                               \
+    }
+
 }  // namespace ndwt

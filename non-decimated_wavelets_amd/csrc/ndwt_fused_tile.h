@@ -8,8 +8,8 @@ constexpr int kFused3Variants = 4;
 template <typename T, bool INVERSE, int V> struct Fused3Tile;
 // float, analysis
 template <> struct Fused3Tile<float, false, 0> { static constexpr int TX = 64, TY = 16, NT = 256, RY = 4, WPE = 3; };
-template <> struct Fused3Tile<float, false, 1> { static constexpr int TX = 64, TY = 16, NT = 512, RY = 4, WPE = 4; };
-template <> struct Fused3Tile<float, false, 2> { static constexpr int TX = 64, TY = 16, NT = 512, RY = 4, WPE = 4; };
+template <> struct Fused3Tile<float, false, 1> { static constexpr int TX = 64, TY = 16, NT = 512, RY = 4, WPE = 2; };   // long filters (db5, db6): one column per thread
+template <> struct Fused3Tile<float, false, 2> { static constexpr int TX = 64, TY = 32, NT = 1024, RY = 4, WPE = 4; };  // tall tile, A/B runs
 template <> struct Fused3Tile<float, false, 3> { static constexpr int TX = 64, TY = 16, NT = 256, RY = 4, WPE = 3; };
 // float, synthesis
 template <> struct Fused3Tile<float, true, 0>  { static constexpr int TX = 64, TY = 16, NT = 256, RY = 2, WPE = 2; };
