@@ -172,8 +172,16 @@ def main():
     avg_ms = dom_ms / max(dom_n, 1)
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     names = {0: "fused3_synthesis" if False else "fused3_analysis", 1: "fused3_synthesis", 2: "axis_analysis", 3: "axis_synthesis"}
+    # HBM-side bytes per launch of that kernel from the committed PMC passes (profiles/r01_traffic.json; measured on
+    # this workload, not live) -- null when the run is not the profiled configuration
+    traffic = None
+    try:
+        if world == 1 and [n1, n2, n3] == [512, 512, 512] and a.wname == "db4" and not a.generic:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))[names[dom]]["traffic_bytes"]
+    except Exception:
+        traffic = None
     roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes": bytes_per_launch,
                 "avg_launch_ms": round(avg_ms, 4), "launches": int(dom_n),
                 "other_kernel": {"kernel": names[[k for k in kinds if k != dom][0]],
                                  "avg_launch_ms": round(prof[[k for k in kinds if k != dom][0]][0] / max(prof[[k for k in kinds if k != dom][0]][1], 1), 4)},
