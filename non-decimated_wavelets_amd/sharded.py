@@ -95,6 +95,7 @@ class ShardedNdDwt:
             synthesis_scheme = "scatter" if getattr(self.engine, "supports_scatter", False) else "gather"
         self.scheme = synthesis_scheme
         self.nb = 1 << self.d
+        self._exchange_cache = {}
 
     # ---------------------------------------------------------------------------------- plumbing
     def _owner(self, g):
@@ -104,17 +105,25 @@ class ShardedNdDwt:
         raise AssertionError(g)
 
     def _plan_exchange(self, before, after):
-        """who needs which global planes: list of (dst, side, src, [global planes]) in a rank-independent order"""
-        msgs = []
+        """Who needs which planes.  Returns contiguous segments (dst_rank, side, src_rank, k0, l0, count) in a
+        rank-independent order: `count` planes starting at local plane l0 of src go to position k0 of dst's
+        before- (side 0) or after- (side 1) halo.  Cached per (before, after)."""
+        key = (before, after)
+        segs = self._exchange_cache.get(key)
+        if segs is not None:
+            return segs
+        segs = []
         for q, (lo, hi) in enumerate(self.parts):
-            for side, planes in ((0, range(lo - before, lo)), (1, range(hi, hi + after))):
-                by_src = {}
-                for k, g in enumerate(planes):
-                    gm = g % self.n_outer
-                    by_src.setdefault(self._owner(gm), []).append((k, gm))
-                for p in sorted(by_src):
-                    msgs.append((q, side, p, by_src[p]))
-        return msgs
+            for side, start, n in ((0, lo - before, before), (1, hi, after)):
+                k = 0
+                while k < n:
+                    g = (start + k) % self.n_outer
+                    p = self._owner(g)
+                    run = min(n - k, self.parts[p][1] - g)          # contiguous inside the owner's slab
+                    segs.append((q, side, p, k, g - self.parts[p][0], run))
+                    k += run
+        self._exchange_cache[key] = segs
+        return segs
 
     def _run_p2p(self, ops):
         if not ops:
@@ -123,55 +132,56 @@ class ShardedNdDwt:
             w.wait()
 
     def _fetch_halo(self, t, ax, before, after):
-        """t: local tensor whose dim `ax` is the sharded axis.  Returns (halo_before, halo_after) tensors."""
+        """t: local tensor whose dim `ax` (0 or 1) is the sharded axis.  Returns (halo_before, halo_after).
+        Segments are contiguous plane ranges: with ax == 0 they are sent / received in place (no staging copies)."""
         shp = list(t.shape)
         hb = t.new_empty(shp[:ax] + [before] + shp[ax + 1:])
         ha = t.new_empty(shp[:ax] + [after] + shp[ax + 1:])
         ops, keep, post = [], [], []
-        for q, side, p, items in self._plan_exchange(before, after):
-            ks = [k for k, _ in items]
-            ls = [g - self.parts[p][0] for _, g in items]
+        for q, side, p, k0, l0, n in self._plan_exchange(before, after):
+            if p != self.rank and q != self.rank:
+                continue
+            dst = (hb if side == 0 else ha).narrow(ax, k0, n) if q == self.rank else None
+            src = t.narrow(ax, l0, n) if p == self.rank else None
             if p == self.rank and q == self.rank:                       # own planes (periodic wrap inside the slab)
-                dst = hb if side == 0 else ha
-                dst.index_copy_(ax, torch.tensor(ks, device=t.device), t.index_select(ax, torch.tensor(ls, device=t.device)))
+                dst.copy_(src)
             elif p == self.rank:
-                buf = t.index_select(ax, torch.tensor(ls, device=t.device)).contiguous()
+                buf = src if src.is_contiguous() else src.contiguous()
                 keep.append(buf)
                 ops.append(dist.P2POp(dist.isend, buf, self._global_rank(q), self.group))
-            elif q == self.rank:
-                buf = t.new_empty(shp[:ax] + [len(ks)] + shp[ax + 1:])
-                ops.append(dist.P2POp(dist.irecv, buf, self._global_rank(p), self.group))
-                post.append((hb if side == 0 else ha, ks, buf))
+            else:
+                if dst.is_contiguous():
+                    ops.append(dist.P2POp(dist.irecv, dst, self._global_rank(p), self.group))
+                else:
+                    buf = torch.empty(dst.shape, dtype=dst.dtype, device=dst.device)
+                    ops.append(dist.P2POp(dist.irecv, buf, self._global_rank(p), self.group))
+                    post.append((dst, buf))
         self._run_p2p(ops)
-        for dst, ks, buf in post:
-            dst.index_copy_(ax, torch.tensor(ks, device=t.device), buf)
+        for dst, buf in post:
+            dst.copy_(buf)
         return hb, ha
 
     def _scatter_add(self, ext, before, after):
         """ext: (before + n_local + after, ...) partial sums; planes outside the slab go to their owners and are added.
         Returns the completed local slab (a view of ext)."""
-        ops, keep, post = [], [], []
+        ops, post = [], []
         own = ext.narrow(0, before, self.n_local)
         local_adds = []
         # rank q PRODUCES partial planes for the global planes around its slab; the owner p ADDS them
-        for q, side, p, items in self._plan_exchange(before, after):
-            ks = [k for k, _ in items]
-            ls = [g - self.parts[p][0] for _, g in items]
+        for q, side, p, k0, l0, n in self._plan_exchange(before, after):
             if q == self.rank:
-                src_idx = [k if side == 0 else before + self.n_local + k for k in ks]
-                part = ext.index_select(0, torch.tensor(src_idx, device=ext.device)).contiguous()
+                part = ext.narrow(0, k0 if side == 0 else before + self.n_local + k0, n)   # contiguous view
                 if p == self.rank:
-                    local_adds.append((ls, part))
+                    local_adds.append((l0, n, part))
                 else:
-                    keep.append(part)
                     ops.append(dist.P2POp(dist.isend, part, self._global_rank(p), self.group))
             elif p == self.rank:
-                buf = ext.new_empty([len(ks)] + list(ext.shape[1:]))
+                buf = torch.empty([n] + list(ext.shape[1:]), dtype=ext.dtype, device=ext.device)
                 ops.append(dist.P2POp(dist.irecv, buf, self._global_rank(q), self.group))
-                post.append((ls, buf))
+                post.append((l0, n, buf))
         self._run_p2p(ops)
-        for ls, buf in local_adds + post:
-            own.index_add_(0, torch.tensor(ls, device=ext.device), buf)
+        for l0, n, buf in local_adds + post:
+            own.narrow(0, l0, n).add_(buf)
         return own
 
     def _global_rank(self, r):
