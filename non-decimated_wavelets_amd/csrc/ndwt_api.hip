@@ -114,6 +114,15 @@ static void prof_end(const ndwt_plan* p, hipStream_t s) {
 
 static long long level_stride(const ndwt_plan* p, int lev) { return p->dilation == NDWT_DILATION_ATROUS ? (1LL << (lev - 1)) : 1LL; }
 
+template <typename T> static bool aligned_vec4(const void* ptr) { return ((uintptr_t)ptr % (4 * sizeof(T))) == 0; }
+template <typename T> static int launch_march(bool syn, int L, const MarchArgs<T>& a, const double* lo, const double* hi, hipStream_t s);
+template <> int launch_march<float>(bool syn, int L, const MarchArgs<float>& a, const double* lo, const double* hi, hipStream_t s) {
+    return launch_march_f32(syn, L, a, lo, hi, s);
+}
+template <> int launch_march<double>(bool syn, int L, const MarchArgs<double>& a, const double* lo, const double* hi, hipStream_t s) {
+    return launch_march_f64(syn, L, a, lo, hi, s);
+}
+
 // ------------------------------------------------------------------------------ one axis, one pass
 template <typename T>
 static int axis_pass(const ndwt_plan* p, bool synthesis, int axis, const long long* dims_cur, long long stride, bool wrap,
@@ -138,6 +147,29 @@ static int axis_pass(const ndwt_plan* p, bool synthesis, int axis, const long lo
     a.n_in = wrap ? a.n : a.n + (long long)(f.len - 1) * stride;
     a.total = a.outer * a.n * a.inner;
     if (a.total == 0) return NDWT_OK;
+    // non-contiguous axis, unit tap stride, 4-element aligned runs: march it with the window in registers
+    if (p->path == NDWT_PATH_AUTO && axis > 0 && stride == 1 && a.inner % 4 == 0 && aligned_vec4<T>(in0) &&
+        (!synthesis || aligned_vec4<T>(in1)) && aligned_vec4<T>(out0) && (synthesis || aligned_vec4<T>(out1))) {
+        MarchArgs<T> m;
+        m.in0 = in0; m.in1 = in1; m.out0 = out0; m.out1 = out1;
+        m.inner = a.inner; m.n = a.n; m.n_in = a.n_in; m.outer = a.outer; m.wrap = a.wrap;
+        m.ngroups = a.inner / 4;
+        const long long gblocks = (m.ngroups + 255) / 256;
+        long long want = (4096 + gblocks * m.outer - 1) / (gblocks * m.outer);
+        if (want < 1) want = 1;
+        long long chunk = (m.n + want - 1) / want;
+        const long long min_chunk = 4LL * (f.len - 1) > 8 ? 4LL * (f.len - 1) : 8;
+        if (chunk < min_chunk) chunk = min_chunk;
+        if (chunk > m.n) chunk = m.n;
+        m.chunk = (int)chunk;
+        m.nchunks = (int)((m.n + chunk - 1) / chunk);
+        prof_begin(p, synthesis ? NDWT_KERNEL_AXIS_SYNTHESIS : NDWT_KERNEL_AXIS_ANALYSIS, s);
+        int rc = launch_march<T>(synthesis, f.len, m, synthesis ? f.syn_lo : f.ana_lo, synthesis ? f.syn_hi : f.ana_hi, s);
+        prof_end(p, s);
+        if (rc == 0) return NDWT_OK;
+        if (rc > 0) return fail(NDWT_ERR_HIP, "march kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        // rc < 0: no instantiation / grid too large -> fall through to the element-wise kernel
+    }
     long long nb = (a.total + 255) / 256;
     const long long cap = 256LL * 64;   // grid-stride beyond 64 blocks per CU
     if (nb > cap) nb = cap;
@@ -225,8 +257,6 @@ static FusedTapsD fused_taps(const ndwt_plan* p, int Lp, bool synthesis) {
     }
     return t;
 }
-
-template <typename T> static bool aligned_vec4(const void* ptr) { return ((uintptr_t)ptr % (4 * sizeof(T))) == 0; }
 
 template <typename T> static int launch3(bool inverse, const Fused3Args<T>& a, const FusedTapsD& t, bool vec4, int variant, const void* td, hipStream_t s);
 template <> int launch3<float>(bool inverse, const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, int variant, const void* td, hipStream_t s) {

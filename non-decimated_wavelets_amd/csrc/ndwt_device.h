@@ -1181,4 +1181,109 @@ template <typename T, int L_, bool VEC4_, int WPE_ = 4> struct Inv2S {
     }
 };
 
+// ------------------------------------------------------------------------------------------------
+// One non-contiguous axis per launch, marched with the filter window in registers (no LDS, no halo re-reads):
+// 1 read -> 2 writes (analysis) / 2 reads -> 1 write (synthesis, scatter form).  The array is [outer][N][inner];
+// a thread owns 4 consecutive `inner` elements and marches a chunk of the axis.  Used for the outer axis of 4-D
+// volumes and for the outer axes of the per-axis path (complex data included: inner then carries the factor 2).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int L> struct MarchTaps {
+    T lo[L];
+    T hi[L];
+};
+template <typename T> struct MarchArgs {
+    const T* in0;          // analysis: input; synthesis: low band
+    const T* in1;          // synthesis: high band
+    T* out0;               // analysis: low band; synthesis: output
+    T* out1;               // analysis: high band
+    long long inner;       // multiple of 4
+    long long n;           // output length of the axis
+    long long n_in;        // input length (n, or n + L - 1 in slab mode)
+    long long outer;
+    int chunk, nchunks;    // output planes per thread, chunks along the axis
+    int wrap;              // 1 periodic, 0 input starts `left` planes before output plane 0
+    long long ngroups;     // inner / 4
+};
+
+template <typename T, int L_, bool SYN> struct AxisMarch {
+    static constexpr int L = L_, NT = 256, WPE = 4;
+    static constexpr int LH = SYN ? L / 2 : L / 2 - 1, RH = SYN ? L / 2 - 1 : L / 2;
+    typedef typename VecT<T>::v4 v4;
+    typedef MarchTaps<T, L> Taps;
+    typedef MarchArgs<T> Args;
+    struct Shared { int unused; };
+    struct State {
+        v4 win[L];         // analysis: raw planes; synthesis: partial sums of the pending outputs
+        v4 nxt[2];
+        long long base_in, base_out;
+        int active;
+    };
+    static NDWT_DEV long long in_plane(const Args& a, long long zraw) {
+        return a.wrap ? modn64(zraw, a.n) : zraw + LH;
+    }
+    static NDWT_DEV void load(State& st, const Args& a, long long zraw) {
+        long long off = st.base_in + in_plane(a, zraw) * a.inner;
+        st.nxt[0] = *reinterpret_cast<const v4*>(a.in0 + off);
+        if constexpr (SYN) st.nxt[1] = *reinterpret_cast<const v4*>(a.in1 + off);
+    }
+    template <int R> static NDWT_DEV void step(State& st, const Args& a, const Taps& tp, long long z, bool emit) {
+        if constexpr (!SYN) {
+            st.win[(R + L - 1) % L] = st.nxt[0];
+            v4 lo = (v4)(T(0)), hi = (v4)(T(0));
+            NDWT_SFOR(j, L)
+                lo += tp.lo[j] * st.win[(R + j) % L];
+                hi += tp.hi[j] * st.win[(R + j) % L];
+            NDWT_SEND
+            if (emit) {
+                long long off = st.base_out + z * a.inner;
+                *reinterpret_cast<v4*>(a.out0 + off) = lo;
+                *reinterpret_cast<v4*>(a.out1 + off) = hi;
+            }
+        } else {
+            NDWT_SFOR(j, L)
+                constexpr int slot = ((R - 1 - j) % L + L) % L;
+                const v4 c = tp.lo[j] * st.nxt[0] + tp.hi[j] * st.nxt[1];
+                if constexpr (j == 0) st.win[slot] = c;
+                else st.win[slot] += c;
+            NDWT_SEND
+            if (emit) *reinterpret_cast<v4*>(a.out0 + st.base_out + z * a.inner) = st.win[((R - L) % L + L) % L];
+        }
+    }
+    template <int R> static NDWT_DEV void dispatch(int r, State& st, const Args& a, const Taps& tp, long long z, bool emit) {
+        if constexpr (R < L) {
+            if (r == R) step<R>(st, a, tp, z, emit);
+            else dispatch<R + 1>(r, st, a, tp, z, emit);
+        }
+    }
+    template <class Exec> static NDWT_DEV void block(Exec& ex, Shared&, const Args& a, const Taps& tp, int bid) {
+        // bid -> (group block along inner, chunk, outer)
+        const long long gblocks = (a.ngroups + NT - 1) / NT;
+        const long long gb = bid % gblocks;
+        const long long rest = bid / gblocks;
+        const int ck = (int)(rest % a.nchunks);
+        const long long o = rest / a.nchunks;
+        const long long zbeg = (long long)ck * a.chunk;
+        const long long zend = zbeg + a.chunk < a.n ? zbeg + a.chunk : a.n;
+        const int nsteps = (int)(zend - zbeg);
+        // analysis: output z needs planes z-LH .. z+RH; the window is primed with the first L-1 of them.
+        // synthesis: input plane q contributes to outputs q-RH .. q+LH; output z is complete after plane z+RH.
+        const int nplanes = nsteps + L - 1;
+        ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+            const long long g = gb * NT + tid;
+            st.active = g < a.ngroups;
+            const long long gi = st.active ? g : 0;
+            st.base_in = o * a.n_in * a.inner + gi * 4;
+            st.base_out = o * a.n * a.inner + gi * 4;
+            load(st, a, zbeg - LH);
+        });
+        for (int p = 0; p < nplanes; ++p) {
+            const int s = p - (L - 1);                    // output step completed by plane p
+            ex.each([&](int, State& st) __attribute__((always_inline)) {
+                dispatch<0>((p + 1) % L, st, a, tp, zbeg + s, s >= 0 && st.active);
+                load(st, a, zbeg - LH + (p + 1 < nplanes ? p + 1 : p));
+            });
+        }
+    }
+};
+
 }  // namespace ndwt

@@ -30,4 +30,8 @@ int launch_inv2_f32(const Fused2Args<float>& a, int Lp, bool vec4, const void* t
 int launch_fwd2_f64(const Fused2Args<double>& a, int Lp, bool vec4, const void* taps_dev, hipStream_t s);
 int launch_inv2_f64(const Fused2Args<double>& a, int Lp, bool vec4, const void* taps_dev, hipStream_t s);
 
+// one non-contiguous axis with the window in registers (taps: kernel-form lo/hi of length L)
+int launch_march_f32(bool syn, int L, const MarchArgs<float>& a, const double* lo, const double* hi, hipStream_t s);
+int launch_march_f64(bool syn, int L, const MarchArgs<double>& a, const double* lo, const double* hi, hipStream_t s);
+
 }  // namespace ndwt

@@ -161,9 +161,50 @@ int emu2(int inverse, int Lp, int vec4, const T* in, T* out, int n1, int n2, int
 #undef CASE2
 }
 
+template <typename T, int L, bool SYN>
+int run_march(ndwt::MarchArgs<T>& a, const double* lo, const double* hi) {
+    typedef ndwt::AxisMarch<T, L, SYN> K;
+    typename K::Taps tp;
+    for (int j = 0; j < L; ++j) { tp.lo[j] = (T)lo[j]; tp.hi[j] = (T)hi[j]; }
+    const long long gblocks = (a.ngroups + K::NT - 1) / K::NT;
+    const long long nblocks = gblocks * a.nchunks * a.outer;
+    for (long long b = 0; b < nblocks; ++b) {
+        typename K::Shared sh;
+        EmuExec<typename K::State, K::NT> ex;
+        K::block(ex, sh, a, tp, (int)b);
+    }
+    return 0;
+}
+
+template <typename T>
+int emu_march(int syn, int L, const T* in0, const T* in1, T* out0, T* out1, long long inner, long long n, long long outer, int chunk,
+              int wrap, const double* lo, const double* hi) {
+    ndwt::MarchArgs<T> a;
+    std::memset(&a, 0, sizeof(a));
+    a.in0 = in0; a.in1 = in1; a.out0 = out0; a.out1 = out1;
+    a.inner = inner; a.n = n; a.n_in = wrap ? n : n + L - 1; a.outer = outer; a.wrap = wrap;
+    a.ngroups = inner / 4;
+    a.chunk = chunk > 0 && chunk < n ? chunk : (int)n;
+    a.nchunks = (int)((n + a.chunk - 1) / a.chunk);
+#define CASEM(LL) case LL: return syn ? run_march<T, LL, true>(a, lo, hi) : run_march<T, LL, false>(a, lo, hi);
+    switch (L) {
+        CASEM(2) CASEM(4) CASEM(8) CASEM(12) CASEM(20)
+        default: return -1;
+    }
+#undef CASEM
+}
+
 }  // namespace
 
 extern "C" {
+int ndwt_emu_march_f32(int syn, int L, const float* in0, const float* in1, float* out0, float* out1, long long inner, long long n,
+                       long long outer, int chunk, int wrap, const double* lo, const double* hi) {
+    return emu_march<float>(syn, L, in0, in1, out0, out1, inner, n, outer, chunk, wrap, lo, hi);
+}
+int ndwt_emu_march_f64(int syn, int L, const double* in0, const double* in1, double* out0, double* out1, long long inner, long long n,
+                       long long outer, int chunk, int wrap, const double* lo, const double* hi) {
+    return emu_march<double>(syn, L, in0, in1, out0, out1, inner, n, outer, chunk, wrap, lo, hi);
+}
 int ndwt_emu2_f32(int inverse, int Lp, int vec4, const float* in, float* out, int n1, int n2, int ychunk, const double* lo,
                   const double* hi, int y_wrap) {
     return emu2<float>(inverse, Lp, vec4, in, out, n1, n2, ychunk, lo, hi, y_wrap);

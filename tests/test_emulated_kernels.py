@@ -146,3 +146,45 @@ def test_emulated_fused2(emu, sizes, wn, vec4, ychunk, l2):
         assert np.isfinite(got).all() and np.abs(got - want_y).max() <= tol * np.abs(want_y).max()
         got = _run2(emu, c, wn, l2, True, dtype, vec4, ychunk)
         assert np.isfinite(got).all() and np.abs(got - want_r).max() <= tol * max(np.abs(want_r).max(), 1.0)
+
+
+MARCH = [
+    # (outer, n, inner), wavelet, chunk
+    ((3, 13, 8), "db1", 0),
+    ((2, 20, 12), "db4", 7),
+    ((1, 37, 1028), "db2", 10),      # more than one 256-thread block along the contiguous run
+    ((2, 24, 4), "db6", 0),
+    ((1, 45, 16), "db10", 9),
+]
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("shape,wn,chunk", MARCH)
+def test_emulated_axis_march(emu, shape, wn, chunk):
+    """register-window kernels for one non-contiguous axis (outer axis of 4-D volumes, per-axis path)"""
+    outer, n, inner = shape
+    rng = np.random.default_rng(5)
+    lo_d, hi_d = orc.wave_filters(wn)
+    L = len(lo_d)
+    t = kernel_taps(wn, 1)
+    x = rng.standard_normal(shape)
+    a_in, d_in = rng.standard_normal(shape), rng.standard_normal(shape)
+    want_lo, want_hi = orc._analysis_axis(x, lo_d, hi_d, 1, 1 / np.sqrt(2.0), 1)
+    want_r = orc._synthesis_axis(a_in, d_in, lo_d, hi_d, 1, 1 / np.sqrt(2.0), 1)
+    for dtype, tol in ((np.float64, 1e-13), (np.float32, 2e-6)):
+        fn = emu.ndwt_emu_march_f32 if dtype == np.float32 else emu.ndwt_emu_march_f64
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_longlong] * 3 + [ctypes.c_int, ctypes.c_int,
+                                                                                                   ctypes.c_void_p, ctypes.c_void_p]
+        P = lambda arr: arr.ctypes.data_as(ctypes.c_void_p)
+        xin = np.ascontiguousarray(x, dtype=dtype)
+        lo = np.full(shape, np.nan, dtype=dtype)
+        hi = np.full(shape, np.nan, dtype=dtype)
+        tl, th = np.ascontiguousarray(t["ana_lo"]), np.ascontiguousarray(t["ana_hi"])
+        assert fn(0, L, P(xin), None, P(lo), P(hi), inner, n, outer, chunk, 1, P(tl), P(th)) == 0
+        assert np.abs(lo - want_lo).max() <= tol * np.abs(want_lo).max() and np.abs(hi - want_hi).max() <= tol * np.abs(want_hi).max()
+        ai, di = np.ascontiguousarray(a_in, dtype=dtype), np.ascontiguousarray(d_in, dtype=dtype)
+        r = np.full(shape, np.nan, dtype=dtype)
+        tl, th = np.ascontiguousarray(t["syn_lo"]), np.ascontiguousarray(t["syn_hi"])
+        assert fn(1, L, P(ai), P(di), P(r), None, inner, n, outer, chunk, 1, P(tl), P(th)) == 0
+        assert np.abs(r - want_r).max() <= tol * np.abs(want_r).max()
