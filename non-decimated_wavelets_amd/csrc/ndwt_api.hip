@@ -147,15 +147,23 @@ static int axis_pass(const ndwt_plan* p, bool synthesis, int axis, const long lo
     a.n_in = wrap ? a.n : a.n + (long long)(f.len - 1) * stride;
     a.total = a.outer * a.n * a.inner;
     if (a.total == 0) return NDWT_OK;
-    // non-contiguous axis, unit tap stride, 4-element aligned runs: march it with the window in registers
-    if (p->path == NDWT_PATH_AUTO && axis > 0 && stride == 1 && a.inner % 4 == 0 && aligned_vec4<T>(in0) &&
+    // Register-window march kernel: needs 4-element aligned contiguous runs below the filtered index.  A dilated
+    // (a-trous) periodic axis whose length is a multiple of the tap stride s is s interleaved unit-stride problems:
+    // view [outer][n][inner] as [outer][n/s][s*inner] and march n/s -- this also covers the contiguous axis for s >= 4.
+    long long m_inner = a.inner, m_n = a.n, m_n_in = a.n_in;
+    bool march_ok = p->path == NDWT_PATH_AUTO;
+    if (stride > 1) {
+        if (wrap && a.n % stride == 0 && a.n / stride >= f.len) { m_inner = a.inner * stride; m_n = a.n / stride; m_n_in = m_n; }
+        else march_ok = false;
+    }
+    if (march_ok && m_inner % 4 == 0 && m_inner >= 4 && aligned_vec4<T>(in0) &&
         (!synthesis || aligned_vec4<T>(in1)) && aligned_vec4<T>(out0) && (synthesis || aligned_vec4<T>(out1))) {
         MarchArgs<T> m;
         m.in0 = in0; m.in1 = in1; m.out0 = out0; m.out1 = out1;
-        m.inner = a.inner; m.n = a.n; m.n_in = a.n_in; m.outer = a.outer; m.wrap = a.wrap;
-        m.ngroups = a.inner / 4;
-        const long long gblocks = (m.ngroups + 255) / 256;
-        long long want = (4096 + gblocks * m.outer - 1) / (gblocks * m.outer);
+        m.inner = m_inner; m.n = m_n; m.n_in = m_n_in; m.outer = a.outer; m.wrap = a.wrap;
+        m.ngroups = m.inner / 4;
+        const long long iblocks = (m.ngroups * m.outer + 255) / 256;
+        long long want = (4096 + iblocks - 1) / iblocks;
         if (want < 1) want = 1;
         long long chunk = (m.n + want - 1) / want;
         const long long min_chunk = 4LL * (f.len - 1) > 8 ? 4LL * (f.len - 1) : 8;

@@ -1256,12 +1256,12 @@ template <typename T, int L_, bool SYN> struct AxisMarch {
         }
     }
     template <class Exec> static NDWT_DEV void block(Exec& ex, Shared&, const Args& a, const Taps& tp, int bid) {
-        // bid -> (group block along inner, chunk, outer)
-        const long long gblocks = (a.ngroups + NT - 1) / NT;
-        const long long gb = bid % gblocks;
-        const long long rest = bid / gblocks;
-        const int ck = (int)(rest % a.nchunks);
-        const long long o = rest / a.nchunks;
+        // bid -> (block of 256 items, chunk); an item = (outer index, group of 4 contiguous elements), so short
+        // contiguous runs (the dilated contiguous axis has inner = stride) still fill the workgroup
+        const long long items = a.ngroups * a.outer;
+        const long long iblocks = (items + NT - 1) / NT;
+        const long long ib = bid % iblocks;
+        const int ck = (int)(bid / iblocks);
         const long long zbeg = (long long)ck * a.chunk;
         const long long zend = zbeg + a.chunk < a.n ? zbeg + a.chunk : a.n;
         const int nsteps = (int)(zend - zbeg);
@@ -1269,9 +1269,10 @@ template <typename T, int L_, bool SYN> struct AxisMarch {
         // synthesis: input plane q contributes to outputs q-RH .. q+LH; output z is complete after plane z+RH.
         const int nplanes = nsteps + L - 1;
         ex.each([&](int tid, State& st) __attribute__((always_inline)) {
-            const long long g = gb * NT + tid;
-            st.active = g < a.ngroups;
-            const long long gi = st.active ? g : 0;
+            const long long it = ib * NT + tid;
+            st.active = it < items;
+            const long long iv = st.active ? it : 0;
+            const long long o = iv / a.ngroups, gi = iv % a.ngroups;
             st.base_in = o * a.n_in * a.inner + gi * 4;
             st.base_out = o * a.n * a.inner + gi * 4;
             load(st, a, zbeg - LH);

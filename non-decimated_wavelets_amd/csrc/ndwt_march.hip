@@ -15,8 +15,8 @@ static int launch_march_L(const MarchArgs<T>& a, const double* lo, const double*
     typedef AxisMarch<T, L, SYN> K;
     typename K::Taps tp;
     for (int j = 0; j < L; ++j) { tp.lo[j] = (T)lo[j]; tp.hi[j] = (T)hi[j]; }
-    const long long gblocks = (a.ngroups + K::NT - 1) / K::NT;
-    const long long nblocks = gblocks * a.nchunks * a.outer;
+    const long long iblocks = (a.ngroups * a.outer + K::NT - 1) / K::NT;
+    const long long nblocks = iblocks * a.nchunks;
     if (nblocks <= 0 || nblocks > 0x7fffffffLL) return -2;
     hipLaunchKernelGGL(march_kernel<K>, dim3((unsigned)nblocks), dim3(K::NT), 0, s, a, tp);
     return (int)hipGetLastError();

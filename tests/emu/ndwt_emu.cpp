@@ -166,8 +166,8 @@ int run_march(ndwt::MarchArgs<T>& a, const double* lo, const double* hi) {
     typedef ndwt::AxisMarch<T, L, SYN> K;
     typename K::Taps tp;
     for (int j = 0; j < L; ++j) { tp.lo[j] = (T)lo[j]; tp.hi[j] = (T)hi[j]; }
-    const long long gblocks = (a.ngroups + K::NT - 1) / K::NT;
-    const long long nblocks = gblocks * a.nchunks * a.outer;
+    const long long iblocks = (a.ngroups * a.outer + K::NT - 1) / K::NT;
+    const long long nblocks = iblocks * a.nchunks;
     for (long long b = 0; b < nblocks; ++b) {
         typename K::Shared sh;
         EmuExec<typename K::State, K::NT> ex;
