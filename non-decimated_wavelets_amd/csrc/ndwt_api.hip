@@ -79,6 +79,7 @@ struct ndwt_plan {
     int zchunk_dir[2];                 // per-direction override of the marched chunk: [0] analysis, [1] synthesis (0 = auto)
     int variant_fwd, variant_inv;      // fused-kernel variants (tuning experiments; same results)
     int num_cus;
+    int fp64_fused;                    // fp64: fused 3-D kernels (1) or the per-axis march kernels (0)
     void* taps_dev[2];                 // device tap tables of the fused kernels: [0] analysis, [1] synthesis (Taps3<T, Lp>)
     // optional per-kernel timing with HIP events on the launch stream (bench.py's roofline figures)
     int profiling;
@@ -121,6 +122,14 @@ template <> int launch_march<float>(bool syn, int L, const MarchArgs<float>& a, 
 }
 template <> int launch_march<double>(bool syn, int L, const MarchArgs<double>& a, const double* lo, const double* hi, hipStream_t s) {
     return launch_march_f64(syn, L, a, lo, hi, s);
+}
+
+template <typename T> static int launch_axisx(bool syn, int L, int ew, const AxisXArgs<T>& a, bool vec4, const double* lo, const double* hi, hipStream_t s);
+template <> int launch_axisx<float>(bool syn, int L, int ew, const AxisXArgs<float>& a, bool vec4, const double* lo, const double* hi, hipStream_t s) {
+    return launch_axisx_f32(syn, L, ew, a, vec4, lo, hi, s);
+}
+template <> int launch_axisx<double>(bool syn, int L, int ew, const AxisXArgs<double>& a, bool vec4, const double* lo, const double* hi, hipStream_t s) {
+    return launch_axisx_f64(syn, L, ew, a, vec4, lo, hi, s);
 }
 
 // ------------------------------------------------------------------------------ one axis, one pass
@@ -178,6 +187,22 @@ static int axis_pass(const ndwt_plan* p, bool synthesis, int axis, const long lo
         if (rc > 0) return fail(NDWT_ERR_HIP, "march kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         // rc < 0: no instantiation / grid too large -> fall through to the element-wise kernel
     }
+    // the contiguous axis (1-D signals, interleaved complex): one wave per row segment, neighbours by lane shifts
+    if (p->path == NDWT_PATH_AUTO && axis == 0 && stride == 1 && wrap && f.len <= 12 && (p->comp == 1 || p->comp == 2) &&
+        a.n * p->comp >= 8 * f.len) {
+        AxisXArgs<T> x;
+        x.in0 = in0; x.in1 = in1; x.out0 = out0; x.out1 = out1;
+        x.row = a.n * p->comp;
+        x.outer = a.outer;
+        x.nseg = 0;
+        const bool v4ok = x.row % 4 == 0 && aligned_vec4<T>(in0) && (!synthesis || aligned_vec4<T>(in1)) && aligned_vec4<T>(out0) &&
+                          (synthesis || aligned_vec4<T>(out1));
+        prof_begin(p, synthesis ? NDWT_KERNEL_AXIS_SYNTHESIS : NDWT_KERNEL_AXIS_ANALYSIS, s);
+        int rc = launch_axisx<T>(synthesis, f.len, (int)p->comp, x, v4ok, synthesis ? f.syn_lo : f.ana_lo, synthesis ? f.syn_hi : f.ana_hi, s);
+        prof_end(p, s);
+        if (rc == 0) return NDWT_OK;
+        if (rc > 0) return fail(NDWT_ERR_HIP, "contiguous-axis kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    }
     long long nb = (a.total + 255) / 256;
     const long long cap = 256LL * 64;   // grid-stride beyond 64 blocks per CU
     if (nb > cap) nb = cap;
@@ -233,6 +258,7 @@ template <typename T> static int generic_synthesis(GenericCtx<T>& c, int axis, i
 // ------------------------------------------------------------------------------------ fused levels
 static bool fused3_eligible(const ndwt_plan* p, long long stride, int* Lp_out) {
     if (p->path != NDWT_PATH_AUTO || p->complexity != NDWT_REAL || stride != 1 || p->ndim < 3) return false;
+    if (p->dtype == NDWT_F64 && !p->fp64_fused) return false;
     int Lp = 2;
     for (int a = 0; a < 3; ++a) Lp = p->filt[a].len > Lp ? p->filt[a].len : Lp;
     if (Lp > 12) return false;   // instantiated tap lengths: 2..12 (db1..db6); longer filters take the per-axis path
@@ -582,6 +608,8 @@ int ndwt_plan_create(ndwt_plan** plan, int ndim, const int64_t* dims, const char
     p->comp = complexity == NDWT_COMPLEX_INTERLEAVED ? 2 : 1;
     p->target_blocks = 2048;
     p->prof = new std::vector<ProfRec>();
+    p->fp64_fused = 0;   // measured: 256^3 fp64 db4 L3 3.8 ms per-axis (march + lane-shift kernels) vs 5.2 ms fused (LDS synthesis kernel)
+    if (const char* v = getenv("NDWT_FP64_FUSED")) p->fp64_fused = atoi(v);
     if (const char* v = getenv("NDWT_VARIANT_FWD")) p->variant_fwd = atoi(v);
     if (const char* v = getenv("NDWT_VARIANT_INV")) p->variant_inv = atoi(v);
     if (const char* v = getenv("NDWT_ZCHUNK_FWD")) p->zchunk_dir[0] = atoi(v);

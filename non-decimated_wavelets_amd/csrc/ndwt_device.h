@@ -1287,4 +1287,96 @@ template <typename T, int L_, bool SYN> struct AxisMarch {
     }
 };
 
+// ------------------------------------------------------------------------------------------------
+// The CONTIGUOUS axis, one launch (1 read -> 2 writes / 2 reads -> 1 write), for data the fused kernels do not cover:
+// 1-D signals and interleaved complex arrays (EW = 2 floats per element: taps step over the (re, im) pairs).
+// A wave owns a segment of one row; lane l holds 4 consecutive scalars and takes its neighbours from the adjacent
+// lanes with DPP wave shifts (several hops for long filters / complex data).  Rows are [outer][n*EW] scalars.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct AxisXArgs {
+    const T* in0;
+    const T* in1;          // synthesis: high band
+    T* out0;
+    T* out1;               // analysis: high band
+    long long row;         // scalars per row = n * EW
+    long long outer;       // rows
+    long long nseg;        // wave segments per row
+};
+
+template <typename T, int L_, bool SYN, int EW_, bool VEC4_> struct AxisX {
+    static constexpr int L = L_, EW = EW_, NT = 256, WPE = 4;
+    static constexpr bool VEC4 = VEC4_;
+    static constexpr int LH = SYN ? L / 2 : L / 2 - 1, RH = SYN ? L / 2 - 1 : L / 2;
+    static constexpr int GL = (LH * EW + 3) / 4, GR = (RH * EW + 3) / 4;
+    static constexpr int WX = 4 * (64 - GL - GR);        // output scalars per wave segment
+    static_assert(GL + GR < 32, "filter too long for one wave");
+    typedef typename VecT<T>::v4 v4;
+    typedef MarchTaps<T, L> Taps;
+    typedef AxisXArgs<T> Args;
+    struct Shared { int unused; };
+    struct State {
+        v4 raw[2];         // this lane's 4 scalars of the input band(s)
+        long long ibase, obase;
+        int xg;            // first scalar of this lane inside the row (may be outside [0,row) for halo lanes)
+        int valid;
+    };
+    static NDWT_DEV void load(State& st, const Args& a) {
+        NDWT_SFOR(b, (SYN ? 2 : 1))
+            const T* p = (b == 0 ? a.in0 : a.in1) + st.ibase;
+            if constexpr (VEC4) {
+                st.raw[b] = *reinterpret_cast<const v4*>(p + modn64(st.xg, a.row));
+            } else {
+                NDWT_SFOR(e, 4)
+                    st.raw[b][e] = p[modn64((long long)st.xg + e, a.row)];
+                NDWT_SEND
+            }
+        NDWT_SEND
+    }
+    template <class Exec> static NDWT_DEV void compute(Exec& ex, State& st, const Args& a, const Taps& tp, int tid) {
+        v4 o0 = (v4)(T(0)), o1 = (v4)(T(0));
+        NDWT_SFOR(e, 4)
+            NDWT_SFOR(j, L)
+                constexpr int idx = e + (j - LH) * EW + 4 * GL;      // scalar index in the wave-local window, >= 0
+                constexpr int D = idx / 4 - GL;
+                constexpr int c = idx % 4;
+                if constexpr (!SYN) {
+                    const T v = NDWT_LANE_SHIFT(ex, tid, D, s.raw[0][c]);
+                    o0[e] += tp.lo[j] * v;
+                    o1[e] += tp.hi[j] * v;
+                } else {
+                    o0[e] += tp.lo[j] * NDWT_LANE_SHIFT(ex, tid, D, s.raw[0][c]);
+                    o0[e] += tp.hi[j] * NDWT_LANE_SHIFT(ex, tid, D, s.raw[1][c]);
+                }
+            NDWT_SEND
+        NDWT_SEND
+        const int lane = tid % 64;
+        if (!st.valid || lane < GL || lane >= 64 - GR || st.xg >= a.row) return;
+        if constexpr (VEC4) {
+            *reinterpret_cast<v4*>(a.out0 + st.obase + st.xg) = o0;
+            if constexpr (!SYN) *reinterpret_cast<v4*>(a.out1 + st.obase + st.xg) = o1;
+        } else {
+            NDWT_SFOR(e, 4)
+                if (st.xg + e < a.row) {
+                    a.out0[st.obase + st.xg + e] = o0[e];
+                    if constexpr (!SYN) a.out1[st.obase + st.xg + e] = o1[e];
+                }
+            NDWT_SEND
+        }
+    }
+    template <class Exec> static NDWT_DEV void block(Exec& ex, Shared&, const Args& a, const Taps& tp, int bid) {
+        ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+            const long long item = (long long)bid * (NT / 64) + tid / 64;       // one wave per (row, segment)
+            const long long nitems = a.outer * a.nseg;
+            st.valid = item < nitems;
+            const long long it = st.valid ? item : nitems - 1;
+            const long long o = it / a.nseg, sg = it % a.nseg;
+            st.ibase = o * a.row;
+            st.obase = o * a.row;
+            st.xg = (int)(sg * WX) + 4 * (tid % 64 - GL);
+            load(st, a);
+        });
+        ex.each([&](int tid, State& st) __attribute__((always_inline)) { compute(ex, st, a, tp, tid); });
+    }
+};
+
 }  // namespace ndwt

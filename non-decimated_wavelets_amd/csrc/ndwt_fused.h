@@ -34,4 +34,8 @@ int launch_inv2_f64(const Fused2Args<double>& a, int Lp, bool vec4, const void* 
 int launch_march_f32(bool syn, int L, const MarchArgs<float>& a, const double* lo, const double* hi, hipStream_t s);
 int launch_march_f64(bool syn, int L, const MarchArgs<double>& a, const double* lo, const double* hi, hipStream_t s);
 
+// the contiguous axis with lane shifts (ew = scalars per element: 1 real, 2 interleaved complex)
+int launch_axisx_f32(bool syn, int L, int ew, const AxisXArgs<float>& a, bool vec4, const double* lo, const double* hi, hipStream_t s);
+int launch_axisx_f64(bool syn, int L, int ew, const AxisXArgs<double>& a, bool vec4, const double* lo, const double* hi, hipStream_t s);
+
 }  // namespace ndwt

@@ -39,3 +39,41 @@ int launch_march_f64(bool syn, int L, const MarchArgs<double>& a, const double* 
 }
 
 }  // namespace ndwt
+
+// ---- contiguous axis (AxisX): 1-D signals and interleaved complex arrays
+namespace ndwt {
+
+template <typename T, int L, bool SYN, int EW>
+static int launch_axisx_L(const AxisXArgs<T>& a0, bool vec4, const double* lo, const double* hi, hipStream_t s) {
+    AxisXArgs<T> a = a0;
+    typedef AxisX<T, L, SYN, EW, true> K;
+    typename K::Taps tp;
+    for (int j = 0; j < L; ++j) { tp.lo[j] = (T)lo[j]; tp.hi[j] = (T)hi[j]; }
+    a.nseg = (a.row + K::WX - 1) / K::WX;
+    const long long nblocks = (a.outer * a.nseg + 3) / 4;
+    if (nblocks <= 0 || nblocks > 0x7fffffffLL || a.row >= (1LL << 30)) return -2;
+    if (vec4) hipLaunchKernelGGL(march_kernel<K>, dim3((unsigned)nblocks), dim3(K::NT), 0, s, a, tp);
+    else hipLaunchKernelGGL((march_kernel<AxisX<T, L, SYN, EW, false>>), dim3((unsigned)nblocks), dim3(K::NT), 0, s, a, tp);
+    return (int)hipGetLastError();
+}
+
+#define NDWT_AXISX_CASE(LL)                                                                                   \
+    case LL:                                                                                                  \
+        if (ew == 1) return syn ? launch_axisx_L<T, LL, true, 1>(a, vec4, lo, hi, s) : launch_axisx_L<T, LL, false, 1>(a, vec4, lo, hi, s); \
+        return syn ? launch_axisx_L<T, LL, true, 2>(a, vec4, lo, hi, s) : launch_axisx_L<T, LL, false, 2>(a, vec4, lo, hi, s);
+template <typename T>
+static int launch_axisx_T(bool syn, int L, int ew, const AxisXArgs<T>& a, bool vec4, const double* lo, const double* hi, hipStream_t s) {
+    if (ew != 1 && ew != 2) return -1;
+    switch (L) {
+        NDWT_AXISX_CASE(2) NDWT_AXISX_CASE(4) NDWT_AXISX_CASE(6) NDWT_AXISX_CASE(8) NDWT_AXISX_CASE(10) NDWT_AXISX_CASE(12)
+        default: return -1;
+    }
+}
+int launch_axisx_f32(bool syn, int L, int ew, const AxisXArgs<float>& a, bool vec4, const double* lo, const double* hi, hipStream_t s) {
+    return launch_axisx_T<float>(syn, L, ew, a, vec4, lo, hi, s);
+}
+int launch_axisx_f64(bool syn, int L, int ew, const AxisXArgs<double>& a, bool vec4, const double* lo, const double* hi, hipStream_t s) {
+    return launch_axisx_T<double>(syn, L, ew, a, vec4, lo, hi, s);
+}
+
+}  // namespace ndwt

@@ -194,9 +194,56 @@ int emu_march(int syn, int L, const T* in0, const T* in1, T* out0, T* out1, long
 #undef CASEM
 }
 
+template <typename T, int L, bool SYN, int EW>
+int run_axisx(ndwt::AxisXArgs<T> a, int vec4, const double* lo, const double* hi) {
+    typedef ndwt::AxisX<T, L, SYN, EW, true> K;
+    ndwt::MarchTaps<T, L> tp;
+    for (int j = 0; j < L; ++j) { tp.lo[j] = (T)lo[j]; tp.hi[j] = (T)hi[j]; }
+    a.nseg = (a.row + K::WX - 1) / K::WX;
+    const long long nblocks = (a.outer * a.nseg + 3) / 4;
+    for (long long b = 0; b < nblocks; ++b) {
+        if (vec4) {
+            typename K::Shared sh;
+            EmuExec<typename K::State, K::NT> ex;
+            K::block(ex, sh, a, tp, (int)b);
+        } else {
+            typedef ndwt::AxisX<T, L, SYN, EW, false> K0;
+            typename K0::Shared sh;
+            EmuExec<typename K0::State, K0::NT> ex;
+            K0::block(ex, sh, a, tp, (int)b);
+        }
+    }
+    return 0;
+}
+
+template <typename T>
+int emu_axisx(int syn, int L, int ew, int vec4, const T* in0, const T* in1, T* out0, T* out1, long long row, long long outer,
+              const double* lo, const double* hi) {
+    ndwt::AxisXArgs<T> a;
+    std::memset(&a, 0, sizeof(a));
+    a.in0 = in0; a.in1 = in1; a.out0 = out0; a.out1 = out1; a.row = row; a.outer = outer;
+#define CASEX(LL)                                                                                                        \
+    case LL:                                                                                                             \
+        if (ew == 1) return syn ? run_axisx<T, LL, true, 1>(a, vec4, lo, hi) : run_axisx<T, LL, false, 1>(a, vec4, lo, hi); \
+        return syn ? run_axisx<T, LL, true, 2>(a, vec4, lo, hi) : run_axisx<T, LL, false, 2>(a, vec4, lo, hi);
+    switch (L) {
+        CASEX(2) CASEX(8) CASEX(12)
+        default: return -1;
+    }
+#undef CASEX
+}
+
 }  // namespace
 
 extern "C" {
+int ndwt_emu_axisx_f32(int syn, int L, int ew, int vec4, const float* in0, const float* in1, float* out0, float* out1, long long row,
+                       long long outer, const double* lo, const double* hi) {
+    return emu_axisx<float>(syn, L, ew, vec4, in0, in1, out0, out1, row, outer, lo, hi);
+}
+int ndwt_emu_axisx_f64(int syn, int L, int ew, int vec4, const double* in0, const double* in1, double* out0, double* out1, long long row,
+                       long long outer, const double* lo, const double* hi) {
+    return emu_axisx<double>(syn, L, ew, vec4, in0, in1, out0, out1, row, outer, lo, hi);
+}
 int ndwt_emu_march_f32(int syn, int L, const float* in0, const float* in1, float* out0, float* out1, long long inner, long long n,
                        long long outer, int chunk, int wrap, const double* lo, const double* hi) {
     return emu_march<float>(syn, L, in0, in1, out0, out1, inner, n, outer, chunk, wrap, lo, hi);

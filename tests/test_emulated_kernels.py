@@ -188,3 +188,45 @@ def test_emulated_axis_march(emu, shape, wn, chunk):
         tl, th = np.ascontiguousarray(t["syn_lo"]), np.ascontiguousarray(t["syn_hi"])
         assert fn(1, L, P(ai), P(di), P(r), None, inner, n, outer, chunk, 1, P(tl), P(th)) == 0
         assert np.abs(r - want_r).max() <= tol * np.abs(want_r).max()
+
+
+AXISX = [
+    # (outer, n), wavelet, complex?, vec4
+    ((3, 40), "db1", False, True),
+    ((2, 300), "db4", False, True),       # two wave segments per row
+    ((2, 37), "db4", False, False),       # odd length: scalar loads/stores
+    ((3, 50), "db4", True, True),         # interleaved complex: taps step over (re, im) pairs, two-lane shifts
+    ((1, 131), "db6", True, False),
+    ((2, 64), "db6", False, True),
+]
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("shape,wn,cplx,vec4", AXISX)
+def test_emulated_contiguous_axis(emu, shape, wn, cplx, vec4):
+    """lane-shift kernel for the contiguous axis (1-D signals, interleaved complex data)"""
+    outer, n = shape
+    rng = np.random.default_rng(6)
+    lo_d, hi_d = orc.wave_filters(wn)
+    L = len(lo_d)
+    t = kernel_taps(wn, 1)
+    mk = (lambda: rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) if cplx else (lambda: rng.standard_normal(shape))
+    x, a_in, d_in = mk(), mk(), mk()
+    want_lo, want_hi = orc._analysis_axis(x, lo_d, hi_d, 1, 1 / np.sqrt(2.0), 1)
+    want_r = orc._synthesis_axis(a_in, d_in, lo_d, hi_d, 1, 1 / np.sqrt(2.0), 1)
+    ew = 2 if cplx else 1
+    for dtype, cdtype, tol in ((np.float64, np.complex128, 1e-13), (np.float32, np.complex64, 2e-6)):
+        fn = emu.ndwt_emu_axisx_f32 if dtype == np.float32 else emu.ndwt_emu_axisx_f64
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p] * 4 + [ctypes.c_longlong] * 2 + [ctypes.c_void_p] * 2
+        P = lambda arr: arr.ctypes.data_as(ctypes.c_void_p)
+        cast = (lambda v: np.ascontiguousarray(v, dtype=cdtype)) if cplx else (lambda v: np.ascontiguousarray(v, dtype=dtype))
+        new = lambda: np.full(shape, np.nan, dtype=cdtype if cplx else dtype)
+        xin, lo, hi = cast(x), new(), new()
+        tl, th = np.ascontiguousarray(t["ana_lo"]), np.ascontiguousarray(t["ana_hi"])
+        assert fn(0, L, ew, int(vec4), P(xin), None, P(lo), P(hi), n * ew, outer, P(tl), P(th)) == 0
+        assert np.abs(lo - want_lo).max() <= tol * np.abs(want_lo).max() and np.abs(hi - want_hi).max() <= tol * np.abs(want_hi).max()
+        ai, di, r = cast(a_in), cast(d_in), new()
+        tl, th = np.ascontiguousarray(t["syn_lo"]), np.ascontiguousarray(t["syn_hi"])
+        assert fn(1, L, ew, int(vec4), P(ai), P(di), P(r), None, n * ew, outer, P(tl), P(th)) == 0
+        assert np.abs(r - want_r).max() <= tol * np.abs(want_r).max()
