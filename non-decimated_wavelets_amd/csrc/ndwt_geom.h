@@ -23,6 +23,8 @@ inline void fused3_geometry(Fused3Args<T>& a, int TX, int TY, int Lp, int target
     if (zc < min_chunk) zc = min_chunk;
     if (zc > a.n3) zc = a.n3;
     if (force_zchunk > 0) zc = force_zchunk < a.n3 ? force_zchunk : a.n3;
+    a.nzc = (a.n3 + zc - 1) / zc;
+    if (force_zchunk <= 0) zc = (a.n3 + a.nzc - 1) / a.nzc;      // equal chunks: the slowest workgroup sets the time
     a.zchunk = zc;
     a.nzc = (a.n3 + zc - 1) / zc;
 }
