@@ -257,21 +257,24 @@ template <typename T> static int generic_synthesis(GenericCtx<T>& c, int axis, i
 
 // ------------------------------------------------------------------------------------ fused levels
 static bool fused3_eligible(const ndwt_plan* p, long long stride, int* Lp_out) {
-    if (p->path != NDWT_PATH_AUTO || p->complexity != NDWT_REAL || stride != 1 || p->ndim < 3) return false;
+    if (p->path != NDWT_PATH_AUTO || stride != 1 || p->ndim < 3) return false;
     if (p->dtype == NDWT_F64 && !p->fp64_fused) return false;
     int Lp = 2;
     for (int a = 0; a < 3; ++a) Lp = p->filt[a].len > Lp ? p->filt[a].len : Lp;
     if (Lp > 12) return false;   // instantiated tap lengths: 2..12 (db1..db6); longer filters take the per-axis path
+    // interleaved complex: fused float kernels with the x taps stepping over (re, im) pairs, tap lengths <= 8
+    if (p->complexity != NDWT_REAL && (p->dtype != NDWT_F32 || Lp > 8 || (p->dims[0] * 2) % 4 != 0)) return false;
     long long nbatch = p->ndim == 4 ? p->dims[3] + 64 : 1;
-    if (!fused3_fits(p->dims[0], p->dims[1], p->dims[2] + 64, nbatch)) return false;
+    if (!fused3_fits(p->dims[0] * p->comp, p->dims[1], p->dims[2] + 64, nbatch)) return false;
     *Lp_out = Lp;
     return true;
 }
 
 static bool fused2_eligible(const ndwt_plan* p, long long stride, int* Lp_out) {
-    if (p->path != NDWT_PATH_AUTO || p->complexity != NDWT_REAL || stride != 1 || p->ndim != 2) return false;
+    if (p->path != NDWT_PATH_AUTO || stride != 1 || p->ndim != 2) return false;
     int Lp = p->filt[0].len > p->filt[1].len ? p->filt[0].len : p->filt[1].len;
     if (Lp > 12) return false;
+    if (p->complexity != NDWT_REAL && (Lp > 8 || (p->dims[0] * 2) % 4 != 0)) return false;
     if (p->dims[0] >= (1LL << 30) || p->dims[1] >= (1LL << 30)) return false;
     *Lp_out = Lp;
     return true;
@@ -292,12 +295,12 @@ static FusedTapsD fused_taps(const ndwt_plan* p, int Lp, bool synthesis) {
     return t;
 }
 
-template <typename T> static int launch3(bool inverse, const Fused3Args<T>& a, const FusedTapsD& t, bool vec4, int variant, const void* td, hipStream_t s);
-template <> int launch3<float>(bool inverse, const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, int variant, const void* td, hipStream_t s) {
-    return inverse ? launch_inv3_f32(a, t, vec4, variant, td, s) : launch_fwd3_f32(a, t, vec4, variant, td, s);
+template <typename T> static int launch3(bool inverse, const Fused3Args<T>& a, const FusedTapsD& t, bool vec4, int variant, int ew, const void* td, hipStream_t s);
+template <> int launch3<float>(bool inverse, const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, int variant, int ew, const void* td, hipStream_t s) {
+    return inverse ? launch_inv3_f32(a, t, vec4, variant, ew, td, s) : launch_fwd3_f32(a, t, vec4, variant, ew, td, s);
 }
-template <> int launch3<double>(bool inverse, const Fused3Args<double>& a, const FusedTapsD& t, bool vec4, int variant, const void* td, hipStream_t s) {
-    return inverse ? launch_inv3_f64(a, t, vec4, variant, td, s) : launch_fwd3_f64(a, t, vec4, variant, td, s);
+template <> int launch3<double>(bool inverse, const Fused3Args<double>& a, const FusedTapsD& t, bool vec4, int variant, int ew, const void* td, hipStream_t s) {
+    return inverse ? launch_inv3_f64(a, t, vec4, variant, ew, td, s) : launch_fwd3_f64(a, t, vec4, variant, ew, td, s);
 }
 
 namespace ndwt {
@@ -316,7 +319,7 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
                       long long in_bstride, long long out_bstride, int z_mode, hipStream_t s) {
     Fused3Args<T> a;
     memset(&a, 0, sizeof a);
-    a.n1 = (int)p->dims[0];
+    a.n1 = (int)(p->dims[0] * p->comp);                   // scalars along x (interleaved complex: 2 per element)
     a.n2 = (int)p->dims[1];
     a.n3 = (int)n3;
     a.nbatch = (int)nbatch;
@@ -340,7 +343,7 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     const void* td = p->taps_dev[inverse ? 1 : 0];
     if (!td) return fail(NDWT_ERR_UNSUPPORTED, "plan has no device tap table");
     prof_begin(p, inverse ? NDWT_KERNEL_FUSED_SYNTHESIS : NDWT_KERNEL_FUSED_ANALYSIS, s);
-    int rc = launch3<T>(inverse, a, t, vec4, variant, td, s);
+    int rc = launch3<T>(inverse, a, t, vec4, variant, (int)p->comp, td, s);
     prof_end(p, s);
     if (rc == -1) return fail(NDWT_ERR_UNSUPPORTED, "no fused kernel instantiated for tap length %d", Lp);
     if (rc != 0) return fail(NDWT_ERR_HIP, "fused kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -348,18 +351,18 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
 }
 
 namespace ndwt {
-int fused2_tile_width(bool inverse, int Lp) {
+int fused2_tile_width(bool inverse, int Lp, int ew) {
     const int LH = inverse ? Lp / 2 : Lp / 2 - 1, RH = inverse ? Lp / 2 - 1 : Lp / 2;
-    return 4 * (64 - (LH + 3) / 4 - (RH + 3) / 4);
+    return 4 * (64 - (LH * ew + 3) / 4 - (RH * ew + 3) / 4);
 }
 }  // namespace ndwt
 
-template <typename T> static int launch2(bool inverse, const Fused2Args<T>& a, int Lp, bool vec4, const void* td, hipStream_t s);
-template <> int launch2<float>(bool inverse, const Fused2Args<float>& a, int Lp, bool vec4, const void* td, hipStream_t s) {
-    return inverse ? launch_inv2_f32(a, Lp, vec4, td, s) : launch_fwd2_f32(a, Lp, vec4, td, s);
+template <typename T> static int launch2(bool inverse, const Fused2Args<T>& a, int Lp, bool vec4, int ew, const void* td, hipStream_t s);
+template <> int launch2<float>(bool inverse, const Fused2Args<float>& a, int Lp, bool vec4, int ew, const void* td, hipStream_t s) {
+    return inverse ? launch_inv2_f32(a, Lp, vec4, ew, td, s) : launch_fwd2_f32(a, Lp, vec4, ew, td, s);
 }
-template <> int launch2<double>(bool inverse, const Fused2Args<double>& a, int Lp, bool vec4, const void* td, hipStream_t s) {
-    return inverse ? launch_inv2_f64(a, Lp, vec4, td, s) : launch_fwd2_f64(a, Lp, vec4, td, s);
+template <> int launch2<double>(bool inverse, const Fused2Args<double>& a, int Lp, bool vec4, int ew, const void* td, hipStream_t s) {
+    return inverse ? launch_inv2_f64(a, Lp, vec4, ew, td, s) : launch_fwd2_f64(a, Lp, vec4, ew, td, s);
 }
 
 // one fused 2-D launch; n2 = output rows; y_wrap=false: inputs carry the y halo (slab mode)
@@ -368,7 +371,7 @@ static int fused2_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
                       long long out_bstride, bool y_wrap, hipStream_t s) {
     Fused2Args<T> a;
     memset(&a, 0, sizeof a);
-    a.n1 = (int)p->dims[0];
+    a.n1 = (int)(p->dims[0] * p->comp);
     a.n2 = (int)n2;
     a.nbatch = 1;
     a.in_bstride = in_bstride;
@@ -378,11 +381,11 @@ static int fused2_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     const int nin = inverse ? 4 : 1, nout = inverse ? 1 : 4;
     for (int b = 0; b < nin; ++b) { a.in[b] = in[b]; vec4 = vec4 && aligned_vec4<T>(in[b]); }
     for (int b = 0; b < nout; ++b) { a.out[b] = out[b]; vec4 = vec4 && aligned_vec4<T>(out[b]); }
-    fused2_geometry(a, fused2_tile_width(inverse, Lp), Lp, p->target_blocks * 2, p->force_zchunk);
+    fused2_geometry(a, fused2_tile_width(inverse, Lp, (int)p->comp), Lp, p->target_blocks * 2, p->force_zchunk);
     const void* td = p->taps_dev[inverse ? 1 : 0];
     if (!td) return fail(NDWT_ERR_UNSUPPORTED, "plan has no device tap table");
     prof_begin(p, inverse ? NDWT_KERNEL_FUSED_SYNTHESIS : NDWT_KERNEL_FUSED_ANALYSIS, s);
-    int rc = launch2<T>(inverse, a, Lp, vec4, td, s);
+    int rc = launch2<T>(inverse, a, Lp, vec4, (int)p->comp, td, s);
     prof_end(p, s);
     if (rc == -1) return fail(NDWT_ERR_UNSUPPORTED, "no fused 2-D kernel instantiated for tap length %d", Lp);
     if (rc != 0) return fail(NDWT_ERR_HIP, "fused 2-D kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -401,7 +404,7 @@ static int analysis_level(ndwt_plan* p, const T* in, T* const* out, long long st
     int Lp = 0;
     // slab mode hands over exactly (L_top-1) halo planes: the fused kernel marches with the padded length
     if (fused3_eligible(p, stride, &Lp) && !(slab && d == 3 && ftop.len != Lp)) {
-        const long long vol3 = p->dims[0] * p->dims[1] * p->dims[2];
+        const long long vol3 = p->comp * p->dims[0] * p->dims[1] * p->dims[2];
         if (d == 3) {
             const T* ins[8] = {in};
             return fused3_run<T>(p, false, Lp, ins, out, p->dims[2], 1, vol_in, p->vol, slab ? 0 : 1, s);
@@ -445,7 +448,7 @@ static int synthesis_level(ndwt_plan* p, const T* const* in, T* out, long long s
     const long long vol_in = p->vol / n_top * n_top_in;
     int Lp = 0;
     if (fused3_eligible(p, stride, &Lp) && !(slab && d == 3 && ftop.len != Lp)) {
-        const long long vol3 = p->dims[0] * p->dims[1] * p->dims[2];
+        const long long vol3 = p->comp * p->dims[0] * p->dims[1] * p->dims[2];
         if (d == 3) {
             T* outs[8] = {out};
             return fused3_run<T>(p, true, Lp, in, outs, p->dims[2], 1, vol_in, p->vol, slab ? 0 : 1, s);

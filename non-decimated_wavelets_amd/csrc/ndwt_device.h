@@ -242,14 +242,16 @@ template <int RSB> struct RowPair {
 };
 
 // ---------------------------------------------------------------------------------- analysis ----
-template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, int WPE_ = 2> struct Fwd3 {
-    static constexpr int L = L_, TX = TX_, TY = TY_, NT = NT_, RY = RY_;
+// EW = scalars per element along x: 1 real, 2 interleaved complex (n1 then counts scalars and the x taps step over
+// (re, im) pairs; the y and z stages are component-wise and do not change)
+template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, int WPE_ = 2, int EW_ = 1> struct Fwd3 {
+    static constexpr int L = L_, TX = TX_, TY = TY_, NT = NT_, RY = RY_, EW = EW_;
     static constexpr bool VEC4 = VEC4_;
     static constexpr int NE = VEC4 ? 1 : 4;              // offsets kept per column
     static constexpr int WPE = WPE_;                     // waves per SIMD the register budget is sized for
     static constexpr int LH = L / 2 - 1;                 // samples left of the output index
     static constexpr int RH = L / 2;                     // samples right of it
-    static constexpr int GL = (LH + 3) / 4, GR = (RH + 3) / 4;   // halo in groups of 4 x
+    static constexpr int GL = (LH * EW + 3) / 4, GR = (RH * EW + 3) / 4;   // halo in groups of 4 x
     static constexpr int W = TX + 4 * (GL + GR);         // haloed tile width (pairs per LDS row)
     static constexpr int NG = W / 4;
     static constexpr int NR = TY + L - 1;                // haloed tile rows
@@ -401,8 +403,8 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
                 v2 lo = (v2)(T(0)), hi = (v2)(T(0));
                 NDWT_UNROLL
                 for (int j = 0; j < L; ++j) {
-                    lo += tp.lo[0][j] * v[4 * GL + e - LH + j];
-                    hi += tp.hi[0][j] * v[4 * GL + e - LH + j];
+                    lo += tp.lo[0][j] * v[4 * GL + e + (j - LH) * EW];
+                    hi += tp.hi[0][j] * v[4 * GL + e + (j - LH) * EW];
                 }
                 o00[e] = lo.x; o01[e] = lo.y; o10[e] = hi.x; o11[e] = hi.y;
             }
@@ -454,7 +456,8 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
 // x-synthesis and y-synthesis go through LDS on the haloed tile (the 2^3 bands are read with an
 // x/y halo, mostly from L2), the z-synthesis window (L planes of (a,d) pairs) stays in registers.
 // Per new plane: for y-bit 0,1 { raw 4 bands -> LDS; x-synth -> xs[y-bit] } ; y-synth -> P ; z-synth.
-template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, int WPE_ = 2> struct Inv3 {
+template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, int WPE_ = 2, int EW_ = 1> struct Inv3 {
+    static_assert(EW_ == 1, "the LDS synthesis kernel handles real data only");
     static constexpr int L = L_, TX = TX_, TY = TY_, NT = NT_, RY = RY_;
     static constexpr bool VEC4 = VEC4_;
     static constexpr int NE = VEC4 ? 1 : 4;
@@ -708,13 +711,13 @@ template <int D, typename T> __device__ __forceinline__ T lane_shift(T v) {
 #define NDWT_LANE_SHIFT(ex, tid, D, expr_of_s) (lane_shift<D>([&](const State& s) { return (expr_of_s); }(st)))
 #endif
 
-template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, int WPE_ = 2> struct Inv3S {
-    static constexpr int L = L_, TX = TX_, TY = TY_, NT = NT_, RY = RY_;
+template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, int WPE_ = 2, int EW_ = 1> struct Inv3S {
+    static constexpr int L = L_, TX = TX_, TY = TY_, NT = NT_, RY = RY_, EW = EW_;
     static constexpr bool VEC4 = VEC4_;
     static constexpr int NE = VEC4 ? 1 : 4;
     static constexpr int WPE = WPE_;
     static constexpr int LH = L / 2, RH = L / 2 - 1;
-    static constexpr int GL = (LH + 3) / 4, GR = (RH + 3) / 4;
+    static constexpr int GL = (LH * EW + 3) / 4, GR = (RH * EW + 3) / 4;
     static constexpr int NG = TX / 4 + GL + GR;          // lanes per haloed row
     static constexpr int NR = TY + L - 1;
     static constexpr int RPW = 64 / NG;                  // rows per wave
@@ -812,10 +815,13 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
                     v2 wa = {NDWT_LANE_SHIFT(ex, tid, D, s.raw[k][0 + 2 * yb][c]), NDWT_LANE_SHIFT(ex, tid, D, s.raw[k][4 + 2 * yb][c])};
                     v2 wd = {NDWT_LANE_SHIFT(ex, tid, D, s.raw[k][1 + 2 * yb][c]), NDWT_LANE_SHIFT(ex, tid, D, s.raw[k][5 + 2 * yb][c])};
                     NDWT_SFOR(e, 4)
-                        constexpr int j = i - (4 * GL + e - LH);
-                        if constexpr (j >= 0 && j < L) {
-                            acc[e] += tp.lo[0][j] * wa;
-                            acc[e] += tp.hi[0][j] * wd;
+                        constexpr int dj = i - 4 * GL - e;                 // = (j - LH) * EW
+                        if constexpr (dj % EW == 0) {
+                            constexpr int j = dj / EW + LH;
+                            if constexpr (j >= 0 && j < L) {
+                                acc[e] += tp.lo[0][j] * wa;
+                                acc[e] += tp.hi[0][j] * wd;
+                            }
                         }
                     NDWT_SEND
                 NDWT_SEND
@@ -948,12 +954,12 @@ template <typename T> NDWT_DEV Tile2Coord decode_tile2(const Fused2Args<T>& a, i
     return tc;
 }
 
-template <typename T, int L_, bool VEC4_, int WPE_ = 4> struct Fwd2S {
-    static constexpr int L = L_, NT = 64, WPE = WPE_;
+template <typename T, int L_, bool VEC4_, int WPE_ = 4, int EW_ = 1> struct Fwd2S {
+    static constexpr int L = L_, NT = 64, WPE = WPE_, EW = EW_;
     static constexpr bool VEC4 = VEC4_;
     static constexpr int NE = VEC4 ? 1 : 4;
     static constexpr int LH = L / 2 - 1, RH = L / 2;
-    static constexpr int GL = (LH + 3) / 4, GR = (RH + 3) / 4;
+    static constexpr int GL = (LH * EW + 3) / 4, GR = (RH * EW + 3) / 4;
     static constexpr int WX = 4 * (64 - GL - GR);        // output columns per wave
     static constexpr int XV = 4 * (1 + GL + GR);
     typedef typename VecT<T>::v2 v2;
@@ -1019,14 +1025,16 @@ template <typename T, int L_, bool VEC4_, int WPE_ = 4> struct Fwd2S {
         NDWT_SFOR(i, XV)
             constexpr int D = i / 4 - GL;
             constexpr int c = i % 4;
-            constexpr int jlo = i - (4 * GL + 3 - LH), jhi = i - (4 * GL - LH);
-            if constexpr (jhi >= 0 && jlo < L) {
+            {
                 v2 v = {NDWT_LANE_SHIFT(ex, tid, D, s.yz[c].x), NDWT_LANE_SHIFT(ex, tid, D, s.yz[c].y)};
                 NDWT_SFOR(e, 4)
-                    constexpr int j = i - (4 * GL + e - LH);
-                    if constexpr (j >= 0 && j < L) {
-                        xlo[e] += tp.lo[0][j] * v;
-                        xhi[e] += tp.hi[0][j] * v;
+                    constexpr int dj = i - 4 * GL - e;                     // = (j - LH) * EW
+                    if constexpr (dj % EW == 0) {
+                        constexpr int j = dj / EW + LH;
+                        if constexpr (j >= 0 && j < L) {
+                            xlo[e] += tp.lo[0][j] * v;
+                            xhi[e] += tp.hi[0][j] * v;
+                        }
                     }
                 NDWT_SEND
             }
@@ -1069,12 +1077,12 @@ template <typename T, int L_, bool VEC4_, int WPE_ = 4> struct Fwd2S {
     }
 };
 
-template <typename T, int L_, bool VEC4_, int WPE_ = 4> struct Inv2S {
-    static constexpr int L = L_, NT = 64, WPE = WPE_;
+template <typename T, int L_, bool VEC4_, int WPE_ = 4, int EW_ = 1> struct Inv2S {
+    static constexpr int L = L_, NT = 64, WPE = WPE_, EW = EW_;
     static constexpr bool VEC4 = VEC4_;
     static constexpr int NE = VEC4 ? 1 : 4;
     static constexpr int LH = L / 2, RH = L / 2 - 1;
-    static constexpr int GL = (LH + 3) / 4, GR = (RH + 3) / 4;
+    static constexpr int GL = (LH * EW + 3) / 4, GR = (RH * EW + 3) / 4;
     static constexpr int WX = 4 * (64 - GL - GR);
     static constexpr int XV = 4 * (1 + GL + GR);
     typedef typename VecT<T>::v2 v2;
@@ -1117,15 +1125,17 @@ template <typename T, int L_, bool VEC4_, int WPE_ = 4> struct Inv2S {
         NDWT_SFOR(i, XV)
             constexpr int D = i / 4 - GL;
             constexpr int c = i % 4;
-            constexpr int jlo = i - (4 * GL + 3 - LH), jhi = i - (4 * GL - LH);
-            if constexpr (jhi >= 0 && jlo < L) {
+            {
                 v2 wa = {NDWT_LANE_SHIFT(ex, tid, D, s.raw[0][c]), NDWT_LANE_SHIFT(ex, tid, D, s.raw[2][c])};   // x-bit 0
                 v2 wd = {NDWT_LANE_SHIFT(ex, tid, D, s.raw[1][c]), NDWT_LANE_SHIFT(ex, tid, D, s.raw[3][c])};   // x-bit 1
                 NDWT_SFOR(e, 4)
-                    constexpr int j = i - (4 * GL + e - LH);
-                    if constexpr (j >= 0 && j < L) {
-                        P[e] += tp.lo[0][j] * wa;
-                        P[e] += tp.hi[0][j] * wd;
+                    constexpr int dj = i - 4 * GL - e;
+                    if constexpr (dj % EW == 0) {
+                        constexpr int j = dj / EW + LH;
+                        if constexpr (j >= 0 && j < L) {
+                            P[e] += tp.lo[0][j] * wa;
+                            P[e] += tp.hi[0][j] * wd;
+                        }
                     }
                 NDWT_SEND
             }

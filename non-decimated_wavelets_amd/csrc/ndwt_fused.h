@@ -18,17 +18,17 @@ struct FusedTapsD {       // per axis (0 = x, 1 = y, 2 = z), zero-padded to Lp, 
 // tile shape a variant uses (for the launch geometry)
 void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int* TY);
 
-int launch_fwd3_f32(const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, int variant, const void* taps_dev, hipStream_t s);
-int launch_inv3_f32(const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, int variant, const void* taps_dev, hipStream_t s);
-int launch_fwd3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4, int variant, const void* taps_dev, hipStream_t s);
-int launch_inv3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4, int variant, const void* taps_dev, hipStream_t s);
+int launch_fwd3_f32(const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, int variant, int ew, const void* taps_dev, hipStream_t s);
+int launch_inv3_f32(const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, int variant, int ew, const void* taps_dev, hipStream_t s);
+int launch_fwd3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4, int variant, int ew, const void* taps_dev, hipStream_t s);
+int launch_inv3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4, int variant, int ew, const void* taps_dev, hipStream_t s);
 
 // fused 2-D kernels (register-only, one wave per tile)
-int fused2_tile_width(bool inverse, int Lp);
-int launch_fwd2_f32(const Fused2Args<float>& a, int Lp, bool vec4, const void* taps_dev, hipStream_t s);
-int launch_inv2_f32(const Fused2Args<float>& a, int Lp, bool vec4, const void* taps_dev, hipStream_t s);
-int launch_fwd2_f64(const Fused2Args<double>& a, int Lp, bool vec4, const void* taps_dev, hipStream_t s);
-int launch_inv2_f64(const Fused2Args<double>& a, int Lp, bool vec4, const void* taps_dev, hipStream_t s);
+int fused2_tile_width(bool inverse, int Lp, int ew);
+int launch_fwd2_f32(const Fused2Args<float>& a, int Lp, bool vec4, int ew, const void* taps_dev, hipStream_t s);
+int launch_inv2_f32(const Fused2Args<float>& a, int Lp, bool vec4, int ew, const void* taps_dev, hipStream_t s);
+int launch_fwd2_f64(const Fused2Args<double>& a, int Lp, bool vec4, int ew, const void* taps_dev, hipStream_t s);
+int launch_inv2_f64(const Fused2Args<double>& a, int Lp, bool vec4, int ew, const void* taps_dev, hipStream_t s);
 
 // one non-contiguous axis with the window in registers (taps: kernel-form lo/hi of length L)
 int launch_march_f32(bool syn, int L, const MarchArgs<float>& a, const double* lo, const double* hi, hipStream_t s);

@@ -1,7 +1,8 @@
 // fused 3-D fwd level, double
 #include "ndwt_fused_kernels.h"
 namespace ndwt {
-int launch_fwd3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4, int variant, const void* taps_dev, hipStream_t s) {
+int launch_fwd3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4, int variant, int ew, const void* taps_dev, hipStream_t s) {
+    if (ew != 1) return -1;
     NDWT_FUSED_SWITCH(Fwd3, Fwd3, false, double)
 }
 }  // namespace ndwt

@@ -42,6 +42,9 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
 
 #define NDWT_FUSED2_CASE(KIND, T, LL)                                                        \
     case LL:                                                                                 \
+        if (ew == 2)                                                                         \
+            return vec4 ? launch_fused2<KIND<T, LL, true, (sizeof(T) == 8 ? 2 : 4), 2>>(a, taps_dev, s)   \
+                        : launch_fused2<KIND<T, LL, false, (sizeof(T) == 8 ? 2 : 4), 2>>(a, taps_dev, s); \
         return vec4 ? launch_fused2<KIND<T, LL, true, (sizeof(T) == 8 ? 2 : 4)>>(a, taps_dev, s) : launch_fused2<KIND<T, LL, false, (sizeof(T) == 8 ? 2 : 4)>>(a, taps_dev, s);
 #define NDWT_FUSED2_SWITCH(KIND, T)   \
     switch (Lp) {                     \
@@ -58,6 +61,14 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
 #define NDWT_FUSED_K(KIND, INV, T, LL, V, VEC)                                                               \
     KIND<T, LL, Fused3Tile<T, INV, V>::TX, Fused3Tile<T, INV, V>::TY, Fused3Tile<T, INV, V>::NT,             \
          Fused3Tile<T, INV, V>::RY, VEC, Fused3Tile<T, INV, V>::WPE>
+// interleaved complex (2 scalars per x element)
+#define NDWT_FUSED_KC(KIND, INV, T, LL, V, VEC)                                                              \
+    KIND<T, LL, Fused3Tile<T, INV, V>::TX, Fused3Tile<T, INV, V>::TY, Fused3Tile<T, INV, V>::NT,             \
+         Fused3Tile<T, INV, V>::RY, VEC, Fused3Tile<T, INV, V>::WPE, 2>
+#define NDWT_FUSED_CASE_C(KIND, INV, T, LL, V)                                                                \
+    case LL:                                                                                                 \
+        return vec4 ? launch_fused3<NDWT_FUSED_KC(KIND, INV, T, LL, V, true)>(a, t, taps_dev, s)             \
+                    : launch_fused3<NDWT_FUSED_KC(KIND, INV, T, LL, V, false)>(a, t, taps_dev, s);
 
 #define NDWT_FUSED_CASE(KIND, INV, T, LL, V)                                                                  \
     case LL:                                                                                                 \
@@ -86,6 +97,15 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
 // float synthesis: the lane-shift kernel on a tall 64x32 tile (1024 threads, one workgroup per CU) is the default;
 // variant 2 = the same kernel on 64x16 / 256 threads, variant 3 = the LDS kernel (A/B runs, db4 only)
 #define NDWT_FUSED_SWITCH_INV_F32(T)                                      \
+    if (ew == 2) {                                                        \
+        switch (t.Lp) {                                                   \
+            NDWT_FUSED_CASE_C(Inv3S, true, T, 2, 1)                       \
+            NDWT_FUSED_CASE_C(Inv3S, true, T, 4, 1)                       \
+            NDWT_FUSED_CASE_C(Inv3S, true, T, 6, 1)                       \
+            NDWT_FUSED_CASE_C(Inv3S, true, T, 8, 1)                       \
+            default: return -1;                                           \
+        }                                                                 \
+    }                                                                     \
     if (variant == 2 && t.Lp == 8) { switch (t.Lp) { NDWT_FUSED_CASE(Inv3S, true, T, 8, 2) } }  \
     if (variant == 3 && t.Lp == 8) { switch (t.Lp) { NDWT_FUSED_CASE(Inv3, true, T, 8, 3) } }   \
     switch (t.Lp) {                                                       \
@@ -101,6 +121,15 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
 // float analysis: 256-thread kernel for tap lengths <= 8, 512 threads (one column per thread) for 10 and 12;
 // variant 2 = tall 64x32 tile with 1024 threads (A/B runs)
 #define NDWT_FUSED_SWITCH_FWD_F32(T)                                      \
+    if (ew == 2) {                                                        \
+        switch (t.Lp) {                                                   \
+            NDWT_FUSED_CASE_C(Fwd3, false, T, 2, 0)                       \
+            NDWT_FUSED_CASE_C(Fwd3, false, T, 4, 0)                       \
+            NDWT_FUSED_CASE_C(Fwd3, false, T, 6, 0)                       \
+            NDWT_FUSED_CASE_C(Fwd3, false, T, 8, 0)                       \
+            default: return -1;                                           \
+        }                                                                 \
+    }                                                                     \
     if (variant == 2) { switch (t.Lp) { NDWT_FUSED_CASE(Fwd3, false, T, 8, 2) NDWT_FUSED_CASE(Fwd3, false, T, 12, 2) } }  \
     switch (t.Lp) {                                                       \
         NDWT_FUSED_CASE(Fwd3, false, T, 2, 0)                             \

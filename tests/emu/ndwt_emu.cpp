@@ -49,12 +49,12 @@ int run(ndwt::Fused3Args<T>& a, const double* lo, const double* hi) {
     return 0;
 }
 
-template <typename T, template <typename, int, int, int, int, int, bool, int> class KIND, int TX, int TY, int NT, int RY, bool ALL>
+template <typename T, template <typename, int, int, int, int, int, bool, int, int> class KIND, int TX, int TY, int NT, int RY, bool ALL, int EW = 1>
 int dispatch(int Lp, int vec4, ndwt::Fused3Args<T>& a, const double* lo, const double* hi) {
 #define CASE(LL)                                                              \
     case LL:                                                                  \
-        return vec4 ? run<KIND<T, LL, TX, TY, NT, RY, true, 2>, T>(a, lo, hi)    \
-                    : run<KIND<T, LL, TX, TY, NT, RY, false, 2>, T>(a, lo, hi);
+        return vec4 ? run<KIND<T, LL, TX, TY, NT, RY, true, 2, EW>, T>(a, lo, hi)    \
+                    : run<KIND<T, LL, TX, TY, NT, RY, false, 2, EW>, T>(a, lo, hi);
     if constexpr (ALL) {
         switch (Lp) {
             CASE(2) CASE(4) CASE(6) CASE(8) CASE(12)
@@ -71,7 +71,7 @@ int dispatch(int Lp, int vec4, ndwt::Fused3Args<T>& a, const double* lo, const d
 
 template <typename T>
 int emu3(int inverse, int Lp, int vec4, const T* in, T* out, int n1, int n2, int n3, int nbatch, int zchunk,
-         const double* lo, const double* hi, int z_wrap, int small_tile, int variant) {
+         const double* lo, const double* hi, int z_wrap, int small_tile, int variant, int ew) {
     ndwt::Fused3Args<T> a;
     std::memset(&a, 0, sizeof(a));
     a.n1 = n1; a.n2 = n2; a.n3 = n3; a.nbatch = nbatch;
@@ -87,6 +87,21 @@ int emu3(int inverse, int Lp, int vec4, const T* in, T* out, int n1, int n2, int
         for (int b = 0; b < 8; ++b) a.in[b] = in + b * vol_in * nbatch;
         a.out[0] = out;
         a.in_bstride = vol_in; a.out_bstride = vol;
+    }
+    if (ew == 2) {      // interleaved complex: n1 counts scalars; lane-shift synthesis and LDS analysis kernels
+        if (small_tile) {
+            ndwt::fused3_geometry(a, 16, 8, Lp, 2048, zchunk);
+            return inverse ? dispatch<T, ndwt::Inv3S, 16, 8, 128, 2, true, 2>(Lp, vec4, a, lo, hi)
+                           : dispatch<T, ndwt::Fwd3, 16, 8, 64, 2, true, 2>(Lp, vec4, a, lo, hi);
+        }
+        typedef ndwt::Fused3Tile<T, false, 0> QF;
+        typedef ndwt::Fused3Tile<T, true, 1> QI;
+        if (inverse) {
+            ndwt::fused3_geometry(a, QI::TX, QI::TY, Lp, 2048, zchunk);
+            return dispatch<T, ndwt::Inv3S, QI::TX, QI::TY, QI::NT, QI::RY, false, 2>(Lp, vec4, a, lo, hi);
+        }
+        ndwt::fused3_geometry(a, QF::TX, QF::TY, Lp, 2048, zchunk);
+        return dispatch<T, ndwt::Fwd3, QF::TX, QF::TY, QF::NT, QF::RY, false, 2>(Lp, vec4, a, lo, hi);
     }
     if (small_tile) {   // a second tile shape exercises different item/lane mappings
         ndwt::fused3_geometry(a, 16, 8, Lp, 2048, zchunk);
@@ -130,7 +145,7 @@ template <class K, typename T> int run2(ndwt::Fused2Args<T>& a, const double* lo
 
 template <typename T>
 int emu2(int inverse, int Lp, int vec4, const T* in, T* out, int n1, int n2, int ychunk, const double* lo, const double* hi,
-         int y_wrap) {
+         int y_wrap, int ew) {
     ndwt::Fused2Args<T> a;
     std::memset(&a, 0, sizeof(a));
     a.n1 = n1; a.n2 = n2; a.nbatch = 1;
@@ -145,6 +160,22 @@ int emu2(int inverse, int Lp, int vec4, const T* in, T* out, int n1, int n2, int
         for (int b = 0; b < 4; ++b) a.in[b] = in + b * vol_in;
         a.out[0] = out;
     }
+#define CASE2C(LL)                                                                                                            \
+    case LL:                                                                                                                  \
+        if (inverse) {                                                                                                        \
+            ndwt::fused2_geometry(a, ndwt::Inv2S<T, LL, true, 4, 2>::WX, Lp, 64, ychunk);                                      \
+            return vec4 ? run2<ndwt::Inv2S<T, LL, true, 4, 2>, T>(a, lo, hi) : run2<ndwt::Inv2S<T, LL, false, 4, 2>, T>(a, lo, hi); \
+        } else {                                                                                                              \
+            ndwt::fused2_geometry(a, ndwt::Fwd2S<T, LL, true, 4, 2>::WX, Lp, 64, ychunk);                                      \
+            return vec4 ? run2<ndwt::Fwd2S<T, LL, true, 4, 2>, T>(a, lo, hi) : run2<ndwt::Fwd2S<T, LL, false, 4, 2>, T>(a, lo, hi); \
+        }
+    if (ew == 2) {
+        switch (Lp) {
+            CASE2C(2) CASE2C(4) CASE2C(8)
+            default: return -1;
+        }
+    }
+#undef CASE2C
 #define CASE2(LL)                                                                                                       \
     case LL:                                                                                                            \
         if (inverse) {                                                                                                  \
@@ -253,20 +284,20 @@ int ndwt_emu_march_f64(int syn, int L, const double* in0, const double* in1, dou
     return emu_march<double>(syn, L, in0, in1, out0, out1, inner, n, outer, chunk, wrap, lo, hi);
 }
 int ndwt_emu2_f32(int inverse, int Lp, int vec4, const float* in, float* out, int n1, int n2, int ychunk, const double* lo,
-                  const double* hi, int y_wrap) {
-    return emu2<float>(inverse, Lp, vec4, in, out, n1, n2, ychunk, lo, hi, y_wrap);
+                  const double* hi, int y_wrap, int ew) {
+    return emu2<float>(inverse, Lp, vec4, in, out, n1, n2, ychunk, lo, hi, y_wrap, ew);
 }
 int ndwt_emu2_f64(int inverse, int Lp, int vec4, const double* in, double* out, int n1, int n2, int ychunk, const double* lo,
-                  const double* hi, int y_wrap) {
-    return emu2<double>(inverse, Lp, vec4, in, out, n1, n2, ychunk, lo, hi, y_wrap);
+                  const double* hi, int y_wrap, int ew) {
+    return emu2<double>(inverse, Lp, vec4, in, out, n1, n2, ychunk, lo, hi, y_wrap, ew);
 }
 // in/out: band-planar, batch inside band: [band][batch][n3(+halo)][n2][n1]; lo/hi: [3][20] padded kernel-form taps
 int ndwt_emu3_f32(int inverse, int Lp, int vec4, const float* in, float* out, int n1, int n2, int n3, int nbatch,
-                  int zchunk, const double* lo, const double* hi, int z_wrap, int small_tile, int variant) {
-    return emu3<float>(inverse, Lp, vec4, in, out, n1, n2, n3, nbatch, zchunk, lo, hi, z_wrap, small_tile, variant);
+                  int zchunk, const double* lo, const double* hi, int z_wrap, int small_tile, int variant, int ew) {
+    return emu3<float>(inverse, Lp, vec4, in, out, n1, n2, n3, nbatch, zchunk, lo, hi, z_wrap, small_tile, variant, ew);
 }
 int ndwt_emu3_f64(int inverse, int Lp, int vec4, const double* in, double* out, int n1, int n2, int n3, int nbatch,
-                  int zchunk, const double* lo, const double* hi, int z_wrap, int small_tile, int variant) {
-    return emu3<double>(inverse, Lp, vec4, in, out, n1, n2, n3, nbatch, zchunk, lo, hi, z_wrap, small_tile, variant);
+                  int zchunk, const double* lo, const double* hi, int z_wrap, int small_tile, int variant, int ew) {
+    return emu3<double>(inverse, Lp, vec4, in, out, n1, n2, n3, nbatch, zchunk, lo, hi, z_wrap, small_tile, variant, ew);
 }
 }

@@ -29,7 +29,7 @@ def emu():
     return ctypes.CDLL(os.path.join(ROOT, "tests", "emu", target))
 
 
-def _run(emu, x_mat_or_bands, wnames, l2, inverse, dtype, vec4, zchunk, small, z_wrap=1, variant=0):
+def _run(emu, x_mat_or_bands, wnames, l2, inverse, dtype, vec4, zchunk, small, z_wrap=1, variant=0, cplx=False):
     Ls = [len(orc.wave_filters(w)[0]) for w in wnames]
     Lp = max(Ls)
     lo = np.zeros((3, 20))
@@ -38,18 +38,21 @@ def _run(emu, x_mat_or_bands, wnames, l2, inverse, dtype, vec4, zchunk, small, z
         t = kernel_taps(wnames[ax], l2, Lp)
         lo[ax, :Lp] = t["syn_lo" if inverse else "ana_lo"]
         hi[ax, :Lp] = t["syn_hi" if inverse else "ana_hi"]
-    src = to_kernel_order(x_mat_or_bands).astype(dtype)
+    cdt = (np.complex64 if dtype == np.float32 else np.complex128) if cplx else dtype
+    src = to_kernel_order(x_mat_or_bands).astype(cdt)
     if inverse:
         n3, n2, n1 = src.shape[1:]
-        out = np.full((n3, n2, n1), np.nan, dtype=dtype)
+        out = np.full((n3, n2, n1), np.nan, dtype=cdt)
     else:
         n3, n2, n1 = src.shape
-        out = np.full((8, n3, n2, n1), np.nan, dtype=dtype)
+        out = np.full((8, n3, n2, n1), np.nan, dtype=cdt)
+    if cplx:
+        n1 *= 2                       # the kernels see scalars along x
     fn = emu.ndwt_emu3_f32 if dtype == np.float32 else emu.ndwt_emu3_f64
     fn.restype = ctypes.c_int
     rc = fn(int(inverse), Lp, int(vec4), src.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p),
             n1, n2, n3, 1, zchunk, lo.ctypes.data_as(ctypes.c_void_p), hi.ctypes.data_as(ctypes.c_void_p), z_wrap,
-            int(small), int(variant))
+            int(small), int(variant), 2 if cplx else 1)
     assert rc == 0
     return np.transpose(out)
 
@@ -96,7 +99,7 @@ def test_emulated_fused3_synthesis(emu, sizes, wn, vec4, zchunk, small, l2):
             assert np.abs(got - want).max() <= tol * max(np.abs(want).max(), 1.0)
 
 
-def _run2(emu, arr, wnames, l2, inverse, dtype, vec4, ychunk):
+def _run2(emu, arr, wnames, l2, inverse, dtype, vec4, ychunk, cplx=False):
     Ls = [len(orc.wave_filters(w)[0]) for w in wnames]
     Lp = max(Ls)
     lo = np.zeros((3, 20))
@@ -105,17 +108,20 @@ def _run2(emu, arr, wnames, l2, inverse, dtype, vec4, ychunk):
         t = kernel_taps(wnames[ax], l2, Lp)
         lo[ax, :Lp] = t["syn_lo" if inverse else "ana_lo"]
         hi[ax, :Lp] = t["syn_hi" if inverse else "ana_hi"]
-    src = to_kernel_order(arr).astype(dtype)
+    cdt = (np.complex64 if dtype == np.float32 else np.complex128) if cplx else dtype
+    src = to_kernel_order(arr).astype(cdt)
     if inverse:
         n2, n1 = src.shape[1:]
-        out = np.full((n2, n1), np.nan, dtype=dtype)
+        out = np.full((n2, n1), np.nan, dtype=cdt)
     else:
         n2, n1 = src.shape
-        out = np.full((4, n2, n1), np.nan, dtype=dtype)
+        out = np.full((4, n2, n1), np.nan, dtype=cdt)
+    if cplx:
+        n1 *= 2
     fn = emu.ndwt_emu2_f32 if dtype == np.float32 else emu.ndwt_emu2_f64
     fn.restype = ctypes.c_int
     rc = fn(int(inverse), Lp, int(vec4), src.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), n1, n2, ychunk,
-            lo.ctypes.data_as(ctypes.c_void_p), hi.ctypes.data_as(ctypes.c_void_p), 1)
+            lo.ctypes.data_as(ctypes.c_void_p), hi.ctypes.data_as(ctypes.c_void_p), 1, 2 if cplx else 1)
     assert rc == 0
     return np.transpose(out)
 
@@ -230,3 +236,44 @@ def test_emulated_contiguous_axis(emu, shape, wn, cplx, vec4):
         tl, th = np.ascontiguousarray(t["syn_lo"]), np.ascontiguousarray(t["syn_hi"])
         assert fn(1, L, ew, int(vec4), P(ai), P(di), P(r), None, n * ew, outer, P(tl), P(th)) == 0
         assert np.abs(r - want_r).max() <= tol * np.abs(want_r).max()
+
+
+CPLX3 = [
+    ((10, 9, 7), ("db1", "db3", "db2"), False, 0, True),
+    ((24, 17, 12), ("db4", "db4", "db4"), True, 5, True),
+    ((70, 19, 10), ("db4", "db2", "db4"), True, 6, False),     # production tiles (analysis 64x16, synthesis 64x32)
+]
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("sizes,wn,vec4,zchunk,small", CPLX3)
+def test_emulated_fused3_interleaved_complex(emu, sizes, wn, vec4, zchunk, small):
+    """fused 3-D kernels on interleaved complex data (x taps step over (re, im) pairs)"""
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal(sizes) + 1j * rng.standard_normal(sizes)
+    c = rng.standard_normal(tuple(sizes) + (8,)) + 1j * rng.standard_normal(tuple(sizes) + (8,))
+    filt = [orc.wave_filters(w) for w in wn]
+    want_y = orc.spatial_level_dec(x, filt, 1)
+    want_r = orc.spatial_level_rec(c, filt, 1)
+    for dtype, tol in ((np.float64, 1e-13), (np.float32, 2e-6)):
+        got = _run(emu, x, wn, 1, False, dtype, vec4, zchunk, small, cplx=True)
+        assert np.isfinite(got).all() and np.abs(got - want_y).max() <= tol * np.abs(want_y).max()
+        got = _run(emu, c, wn, 1, True, dtype, vec4, zchunk, small, cplx=True)
+        assert np.isfinite(got).all() and np.abs(got - want_r).max() <= tol * np.abs(want_r).max()
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("sizes,wn,vec4,ychunk", [((40, 13), ("db1", "db2"), True, 0), ((150, 20), ("db4", "db4"), True, 7),
+                                                    ((33, 12), ("db4", "db1"), False, 0)])
+def test_emulated_fused2_interleaved_complex(emu, sizes, wn, vec4, ychunk):
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal(sizes) + 1j * rng.standard_normal(sizes)
+    c = rng.standard_normal(tuple(sizes) + (4,)) + 1j * rng.standard_normal(tuple(sizes) + (4,))
+    filt = [orc.wave_filters(w) for w in wn]
+    want_y = orc.spatial_level_dec(x, filt, 0)
+    want_r = orc.spatial_level_rec(c, filt, 0)
+    for dtype, tol in ((np.float64, 1e-13), (np.float32, 2e-6)):
+        got = _run2(emu, x, wn, 0, False, dtype, vec4, ychunk, cplx=True)
+        assert np.isfinite(got).all() and np.abs(got - want_y).max() <= tol * np.abs(want_y).max()
+        got = _run2(emu, c, wn, 0, True, dtype, vec4, ychunk, cplx=True)
+        assert np.isfinite(got).all() and np.abs(got - want_r).max() <= tol * max(np.abs(want_r).max(), 1.0)
