@@ -99,6 +99,15 @@ int ndwt_rec(ndwt_plan* plan, const void* y_dev, void* x_dev, int level, void* s
 int ndwt_dec_host(ndwt_plan* plan, const void* x_host, void* y_host, int level);
 int ndwt_rec_host(ndwt_plan* plan, const void* y_host, void* x_host, int level);
 
+/* Split complex: separate real / imaginary arrays, the layout the reference's gateway receives from MATLAB
+ * (mxGetPr / mxGetPi, nd_dwt_mex.c:55-58,90-93) and hands to nd_dwt_dec / nd_dwt_rec (outR/outI, imageR/imageI,
+ * nddwt.h:13-20).  The plan must be NDWT_REAL (real filters: each part is transformed on its own); the imaginary
+ * pointers may both be NULL (real data).  Device-pointer and host-pointer forms. */
+int ndwt_dec_split(ndwt_plan* plan, const void* x_re, const void* x_im, void* y_re, void* y_im, int level, void* stream);
+int ndwt_rec_split(ndwt_plan* plan, const void* y_re, const void* y_im, void* x_re, void* x_im, int level, void* stream);
+int ndwt_dec_split_host(ndwt_plan* plan, const void* x_re, const void* x_im, void* y_re, void* y_im, int level);
+int ndwt_rec_split_host(ndwt_plan* plan, const void* y_re, const void* y_im, void* x_re, void* x_im, int level);
+
 /* ---- one level on a slab of the outermost axis (multi-GPU building block; no reference counterpart:
  *      the reference is single-process) ------------------------------------------------
  * The plan's dims describe the LOCAL slab (dims[ndim-1] = local planes).  `stride` is the tap stride of

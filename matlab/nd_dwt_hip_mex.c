@@ -9,8 +9,10 @@
  *   wnames   cell array of 'dbK', one per axis (1-D: a single string)
  *   dir      0 forward, nonzero inverse                                  (nd_dwt_mex.c:33,106)
  *   dilation optional 'reference' (default) | 'atrous'
- * Written for the interleaved-complex mex API (R2018a+, mex -R2018a); with split storage call it twice on
- * real(x) and imag(x) -- the filters are real.  Build:  matlab/ndwt_hip_compile.m.
+ * Complex data: with the interleaved-complex mex API (mex -R2018a, MX_HAS_INTERLEAVED_COMPLEX) the array goes through
+ * an NDWT_COMPLEX_INTERLEAVED plan; with the split API of the reference's gateway (mxGetPr / mxGetPi,
+ * nd_dwt_mex.c:55-58) the real and imaginary parts go through ndwt_{dec,rec}_split_host on a real plan.
+ * Build:  matlab/ndwt_hip_compile.m.
  * NOT compiled in the build container (no MATLAB / mex.h there); all behaviour is tested through the C ABI.
  */
 #include <string.h>
@@ -58,7 +60,11 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     }
 
     const int dtype = mxIsSingle(x) ? NDWT_F32 : NDWT_F64;
+#if MX_HAS_INTERLEAVED_COMPLEX
     const int cplx = mxIsComplex(x) ? NDWT_COMPLEX_INTERLEAVED : NDWT_REAL;
+#else
+    const int cplx = NDWT_REAL;                          /* split storage: one real transform per part */
+#endif
     ndwt_plan* plan = NULL;
     if (ndwt_plan_create(&plan, ndim, dims, wn, dtype, cplx, l2, dilation, level, 0) != NDWT_OK) fail("plan");
 
@@ -70,8 +76,15 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     if (ond == 1) od[ond++] = 1;
     plhs[0] = mxCreateNumericArray(ond, od, mxIsSingle(x) ? mxSINGLE_CLASS : mxDOUBLE_CLASS, mxIsComplex(x) ? mxCOMPLEX : mxREAL);
 
+#if MX_HAS_INTERLEAVED_COMPLEX
     int rc = inverse ? ndwt_rec_host(plan, mxGetData(x), mxGetData(plhs[0]), level)
                      : ndwt_dec_host(plan, mxGetData(x), mxGetData(plhs[0]), level);
+#else
+    const void* x_im = mxIsComplex(x) ? mxGetImagData(x) : NULL;
+    void* y_im = mxIsComplex(x) ? mxGetImagData(plhs[0]) : NULL;
+    int rc = inverse ? ndwt_rec_split_host(plan, mxGetData(x), x_im, mxGetData(plhs[0]), y_im, level)
+                     : ndwt_dec_split_host(plan, mxGetData(x), x_im, mxGetData(plhs[0]), y_im, level);
+#endif
     ndwt_plan_destroy(plan);
     if (rc != NDWT_OK) fail(inverse ? "rec" : "dec");
     (void)nlhs;

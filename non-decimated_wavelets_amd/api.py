@@ -83,6 +83,19 @@ class Plan:
     def rec(self, y_ptr, x_ptr, level, stream=0):
         L.check(L.lib().ndwt_rec(self._h, y_ptr, x_ptr, int(level), ctypes.c_void_p(stream)))
 
+    def dec_split(self, x_re, x_im, y_re, y_im, level, stream=0):
+        """split complex (separate re / im device arrays, the mxGetPr / mxGetPi layout); x_im, y_im may be None"""
+        L.check(L.lib().ndwt_dec_split(self._h, x_re, x_im, y_re, y_im, int(level), ctypes.c_void_p(stream)))
+
+    def rec_split(self, y_re, y_im, x_re, x_im, level, stream=0):
+        L.check(L.lib().ndwt_rec_split(self._h, y_re, y_im, x_re, x_im, int(level), ctypes.c_void_p(stream)))
+
+    def dec_split_host(self, x_re, x_im, y_re, y_im, level):
+        L.check(L.lib().ndwt_dec_split_host(self._h, x_re, x_im, y_re, y_im, int(level)))
+
+    def rec_split_host(self, y_re, y_im, x_re, x_im, level):
+        L.check(L.lib().ndwt_rec_split_host(self._h, y_re, y_im, x_re, x_im, int(level)))
+
     def slab_halo(self, stride=1):
         v = [ctypes.c_int64(0) for _ in range(4)]
         L.check(L.lib().ndwt_slab_halo(self._h, int(stride), *[ctypes.byref(t) for t in v]))

@@ -793,6 +793,50 @@ static int host_roundtrip(ndwt_plan* p, bool inverse, const void* src, void* dst
 int ndwt_dec_host(ndwt_plan* p, const void* x, void* y, int level) { return host_roundtrip(p, false, x, y, level); }
 int ndwt_rec_host(ndwt_plan* p, const void* y, void* x, int level) { return host_roundtrip(p, true, y, x, level); }
 
+// Split complex (separate real / imaginary arrays: mxGetPr / mxGetPi of nd_dwt_mex.c:55-58).  The filters are
+// real, so the complex transform is the real transform of each part: a REAL plan is run once per part.
+static int split_check(const ndwt_plan* p) {
+    if (!p) return fail(NDWT_ERR_INVALID_ARG, "null plan");
+    if (p->comp != 1) return fail(NDWT_ERR_INVALID_ARG, "split-complex entry points take a plan created with NDWT_REAL");
+    return NDWT_OK;
+}
+
+int ndwt_dec_split(ndwt_plan* p, const void* x_re, const void* x_im, void* y_re, void* y_im, int level, void* stream) {
+    int rc = split_check(p);
+    if (rc) return rc;
+    if ((x_im == nullptr) != (y_im == nullptr)) return fail(NDWT_ERR_INVALID_ARG, "imaginary input and output must both be given or both be NULL");
+    rc = ndwt_dec(p, x_re, y_re, level, stream);
+    if (rc == NDWT_OK && x_im) rc = ndwt_dec(p, x_im, y_im, level, stream);
+    return rc;
+}
+
+int ndwt_rec_split(ndwt_plan* p, const void* y_re, const void* y_im, void* x_re, void* x_im, int level, void* stream) {
+    int rc = split_check(p);
+    if (rc) return rc;
+    if ((x_im == nullptr) != (y_im == nullptr)) return fail(NDWT_ERR_INVALID_ARG, "imaginary input and output must both be given or both be NULL");
+    rc = ndwt_rec(p, y_re, x_re, level, stream);
+    if (rc == NDWT_OK && y_im) rc = ndwt_rec(p, y_im, x_im, level, stream);
+    return rc;
+}
+
+int ndwt_dec_split_host(ndwt_plan* p, const void* x_re, const void* x_im, void* y_re, void* y_im, int level) {
+    int rc = split_check(p);
+    if (rc) return rc;
+    if ((x_im == nullptr) != (y_im == nullptr)) return fail(NDWT_ERR_INVALID_ARG, "imaginary input and output must both be given or both be NULL");
+    rc = host_roundtrip(p, false, x_re, y_re, level);
+    if (rc == NDWT_OK && x_im) rc = host_roundtrip(p, false, x_im, y_im, level);
+    return rc;
+}
+
+int ndwt_rec_split_host(ndwt_plan* p, const void* y_re, const void* y_im, void* x_re, void* x_im, int level) {
+    int rc = split_check(p);
+    if (rc) return rc;
+    if ((x_im == nullptr) != (y_im == nullptr)) return fail(NDWT_ERR_INVALID_ARG, "imaginary input and output must both be given or both be NULL");
+    rc = host_roundtrip(p, true, y_re, x_re, level);
+    if (rc == NDWT_OK && y_im) rc = host_roundtrip(p, true, y_im, x_im, level);
+    return rc;
+}
+
 int ndwt_slab_halo(const ndwt_plan* p, int stride, int64_t* ab, int64_t* aa, int64_t* sb, int64_t* sa) {
     if (!p || stride < 1) return fail(NDWT_ERR_INVALID_ARG, "bad plan/stride");
     const int L = p->filt[p->ndim - 1].len;

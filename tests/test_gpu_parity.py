@@ -187,6 +187,35 @@ def test_host_pointer_entry_points_of_the_c_abi():
         p.dec(1, 1, 5)
 
 
+def test_split_complex_entry_points_match_the_interleaved_transform():
+    """separate re / im arrays (the mxGetPr / mxGetPi layout of nd_dwt_mex.c:55-58) through ndwt_*_split[_host]"""
+    import ctypes
+    api = __import__("importlib").import_module("non-decimated_wavelets_amd.api")
+    dims, wn, lev = [20, 12, 9], ["db2", "db3", "db1"], 2
+    rng = np.random.default_rng(16)
+    x = rng.standard_normal(dims) + 1j * rng.standard_normal(dims)
+    want = orc.spatial_dec(x, wn, lev, 0)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    p = api.Plan(dims, wn, torch.float64, max_level=lev)
+    xr, xi = np.ascontiguousarray(x.real.T), np.ascontiguousarray(x.imag.T)
+    yr, yi = np.empty((15, 9, 12, 20)), np.empty((15, 9, 12, 20))
+    p.dec_split_host(vp(xr), vp(xi), vp(yr), vp(yi), lev)
+    assert _relerr(yr.T + 1j * yi.T, want) < 1e-12
+    br, bi = np.empty_like(xr), np.empty_like(xi)
+    p.rec_split_host(vp(yr), vp(yi), vp(br), vp(bi), lev)
+    assert _relerr(br + 1j * bi, xr + 1j * xi) < 1e-12
+    # device pointers; real data = NULL imaginary parts
+    tx, ty = torch.from_numpy(xr).cuda(), torch.empty((15, 9, 12, 20), dtype=torch.float64, device="cuda")
+    p.dec_split(tx.data_ptr(), None, ty.data_ptr(), None, lev)
+    torch.cuda.synchronize()
+    assert _relerr(ty.cpu().numpy(), yr) < 1e-14
+    with pytest.raises(ndwt.NdwtError, match="both"):
+        p.dec_split(tx.data_ptr(), tx.data_ptr(), ty.data_ptr(), None, lev)
+    pc = api.Plan(dims, wn, torch.float64, True, max_level=lev)
+    with pytest.raises(ndwt.NdwtError, match="NDWT_REAL"):
+        pc.dec_split(tx.data_ptr(), None, ty.data_ptr(), None, lev)
+
+
 def test_properties_linearity_shift_adjoint():
     torch.manual_seed(0)
     sizes = [48, 36, 40]
