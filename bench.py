@@ -117,7 +117,8 @@ def main():
         kinds = (2, 3) if a.generic else (0, 1)
     else:
         sh = importlib.import_module("non-decimated_wavelets_amd.sharded")
-        eng = sh.ShardedNdDwt([a.wname] * 3, [n1, n2, n3], pres_l2_norm=True, precision="single", group=None, device=dev)
+        eng = sh.ShardedNdDwt([a.wname] * 3, [n1, n2, n3], pres_l2_norm=True, precision="single", group=None, device=dev,
+                              overlap=os.environ.get("NDWT_BENCH_OVERLAP", "1") == "1")   # 0: exchange and compute in sequence (A/B)
         x = torch.randn(eng.n_local, n2, n1, device=dev, dtype=torch.float32)
         plan = eng.plan
         r_holder = {}

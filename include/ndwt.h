@@ -129,6 +129,26 @@ int ndwt_analysis_level_slab_split(ndwt_plan* plan, const void* in_local, const 
                                    void* const* out_bands, int stride, void* stream);
 int ndwt_synthesis_level_slab_ext(ndwt_plan* plan, const void* const* in_bands_local, void* out_ext, int stride, void* stream);
 
+/* Runs of planes of the two calls above, so that the exchange can overlap with the planes that do not wait for it.
+ * analysis_part: n_planes output planes; in_local points at the first of them, halo_before at the (L/2-1) planes
+ *   before it and halo_after at the (L/2) planes after the run -- each may point into the slab itself or into a
+ *   received buffer; out[b] points at the first output plane of band b.
+ * synthesis_part: output planes [e0, e0 + n_out) of the zero-extended synthesis of n_in coefficient planes
+ *   (in_local[b] = first plane of band b; result plane e sums coefficient planes e-(L-1)..e, so planes
+ *   [0, L/2-1) and [n_in + L/2-1, n_in + L-1) are the partial sums owed to the neighbours). */
+int ndwt_analysis_level_slab_part(ndwt_plan* plan, const void* in_local, const void* halo_before, const void* halo_after,
+                                  void* const* out_bands, int stride, int64_t n_planes, void* stream);
+int ndwt_synthesis_level_slab_part(ndwt_plan* plan, const void* const* in_local, int64_t n_in, int64_t e0, int64_t n_out,
+                                   void* out, int stride, void* stream);
+/* Several equal runs in one launch (the two ends of a slab):
+ * analysis_runs: the input carries its halo contiguously (as for ndwt_analysis_level_slab); run r reads from
+ *   in_with_halo + r*run_stride planes and writes n_planes planes at out[b] + r*run_stride planes.
+ * synthesis_runs: run r = planes [e0 + r*e_stride, +n_out) of the zero-extended result, written to out + r*n_out planes. */
+int ndwt_analysis_level_slab_runs(ndwt_plan* plan, const void* in_with_halo, void* const* out_bands, int stride, int64_t n_planes,
+                                  int64_t n_runs, int64_t run_stride, void* stream);
+int ndwt_synthesis_level_slab_runs(ndwt_plan* plan, const void* const* in_local, int64_t n_in, int64_t e0, int64_t e_stride,
+                                   int64_t n_runs, int64_t n_out, void* out, int stride, void* stream);
+
 /* ---- errors ------------------------------------------------------------------------------------------ */
 const char* ndwt_last_error(void); /* thread-local message of the last failing call */
 const char* ndwt_version(void);

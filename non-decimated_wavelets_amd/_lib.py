@@ -23,7 +23,8 @@ EXPORTS = [
     "ndwt_wave_filters", "ndwt_num_bands", "ndwt_level_from_bands", "ndwt_plan_create", "ndwt_plan_destroy",
     "ndwt_plan_set_path", "ndwt_plan_describe", "ndwt_plan_set_tuning", "ndwt_plan_set_profiling", "ndwt_plan_get_profile", "ndwt_dec", "ndwt_rec", "ndwt_dec_host",
     "ndwt_rec_host", "ndwt_dec_split", "ndwt_rec_split", "ndwt_dec_split_host", "ndwt_rec_split_host", "ndwt_slab_halo", "ndwt_analysis_level_slab", "ndwt_synthesis_level_slab",
-    "ndwt_analysis_level_slab_split", "ndwt_synthesis_level_slab_ext", "ndwt_last_error",
+    "ndwt_analysis_level_slab_split", "ndwt_synthesis_level_slab_ext", "ndwt_analysis_level_slab_part",
+    "ndwt_synthesis_level_slab_part", "ndwt_analysis_level_slab_runs", "ndwt_synthesis_level_slab_runs", "ndwt_last_error",
     "ndwt_version",
 ]
 
@@ -87,6 +88,14 @@ def lib() -> ctypes.CDLL:
     L.ndwt_analysis_level_slab_split.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_void_pp,
                                                  ctypes.c_int, ctypes.c_void_p]
     L.ndwt_synthesis_level_slab_ext.argtypes = [ctypes.c_void_p, c_void_pp, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    L.ndwt_analysis_level_slab_part.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_void_pp,
+                                                ctypes.c_int, ctypes.c_int64, ctypes.c_void_p]
+    L.ndwt_synthesis_level_slab_part.argtypes = [ctypes.c_void_p, c_void_pp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                                 ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    L.ndwt_analysis_level_slab_runs.argtypes = [ctypes.c_void_p, ctypes.c_void_p, c_void_pp, ctypes.c_int, ctypes.c_int64,
+                                                ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+    L.ndwt_synthesis_level_slab_runs.argtypes = [ctypes.c_void_p, c_void_pp] + [ctypes.c_int64] * 5 + [ctypes.c_void_p, ctypes.c_int,
+                                                                                                    ctypes.c_void_p]
     L.ndwt_last_error.restype = ctypes.c_char_p
     L.ndwt_version.restype = ctypes.c_char_p
     _lib = L

@@ -114,6 +114,26 @@ class Plan:
         arr = (ctypes.c_void_p * len(in_ptrs))(*in_ptrs)
         L.check(L.lib().ndwt_synthesis_level_slab_ext(self._h, arr, out_ext_ptr, int(stride), ctypes.c_void_p(stream)))
 
+    def analysis_level_slab_part(self, in_ptr, halo_before_ptr, halo_after_ptr, out_ptrs, n_planes, stride=1, stream=0):
+        arr = (ctypes.c_void_p * len(out_ptrs))(*out_ptrs)
+        L.check(L.lib().ndwt_analysis_level_slab_part(self._h, in_ptr, halo_before_ptr, halo_after_ptr, arr, int(stride),
+                                                      int(n_planes), ctypes.c_void_p(stream)))
+
+    def synthesis_level_slab_part(self, in_ptrs, n_in, e0, n_out, out_ptr, stride=1, stream=0):
+        arr = (ctypes.c_void_p * len(in_ptrs))(*in_ptrs)
+        L.check(L.lib().ndwt_synthesis_level_slab_part(self._h, arr, int(n_in), int(e0), int(n_out), out_ptr, int(stride),
+                                                       ctypes.c_void_p(stream)))
+
+    def analysis_level_slab_runs(self, in_ptr, out_ptrs, n_planes, n_runs, run_stride, stride=1, stream=0):
+        arr = (ctypes.c_void_p * len(out_ptrs))(*out_ptrs)
+        L.check(L.lib().ndwt_analysis_level_slab_runs(self._h, in_ptr, arr, int(stride), int(n_planes), int(n_runs), int(run_stride),
+                                                      ctypes.c_void_p(stream)))
+
+    def synthesis_level_slab_runs(self, in_ptrs, n_in, e0, e_stride, n_runs, n_out, out_ptr, stride=1, stream=0):
+        arr = (ctypes.c_void_p * len(in_ptrs))(*in_ptrs)
+        L.check(L.lib().ndwt_synthesis_level_slab_runs(self._h, arr, int(n_in), int(e0), int(e_stride), int(n_runs), int(n_out),
+                                                       out_ptr, int(stride), ctypes.c_void_p(stream)))
+
     def synthesis_level_slab(self, in_ptrs, out_ptr, stride=1, stream=0):
         arr = (ctypes.c_void_p * len(in_ptrs))(*in_ptrs)
         L.check(L.lib().ndwt_synthesis_level_slab(self._h, arr, out_ptr, int(stride), ctypes.c_void_p(stream)))

@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <climits>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -316,9 +317,12 @@ void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int
 // one fused 3-D launch over `nbatch` volumes. n3 = output planes; z_wrap=false: inputs carry the z halo
 template <typename T>
 static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* in, T* const* out, long long n3, long long nbatch,
-                      long long in_bstride, long long out_bstride, int z_mode, hipStream_t s) {
+                      long long in_bstride, long long out_bstride, int z_mode, hipStream_t s, long long zlo = 0, long long zhi = LLONG_MIN, long long zbs = 0) {
     Fused3Args<T> a;
     memset(&a, 0, sizeof a);
+    a.zlo = (int)zlo;                                     // mode 3: input planes outside [zlo, zhi) read as zero
+    a.zhi = (int)(zhi != LLONG_MIN ? zhi : n3 - (Lp - 1));
+    a.zbs = (int)zbs;
     a.n1 = (int)(p->dims[0] * p->comp);                   // scalars along x (interleaved complex: 2 per element)
     a.n2 = (int)p->dims[1];
     a.n3 = (int)n3;
@@ -562,6 +566,34 @@ template <typename T> static int slab_ext_impl(ndwt_plan* p, int Lp, const void*
     return fused3_run<T>(p, true, Lp, (const T* const*)in, outs, n_out, 1, p->vol, p->vol / p->dims[2] * n_out, 3, s);
 }
 
+
+// a run of output planes of the slab transform (the caller offsets the pointers): what lets the halo exchange
+// overlap with the planes that do not depend on it
+template <typename T>
+static int slab_analysis_part_impl(ndwt_plan* p, int Lp, const void* in, const void* hb, const void* ha, void* const* out,
+                                   long long n_planes, hipStream_t s) {
+    const T* ins[8] = {(const T*)in, (const T*)hb, (const T*)ha};
+    return fused3_run<T>(p, false, Lp, ins, (T* const*)out, n_planes, 1, p->vol, p->vol, 2, s);
+}
+
+template <typename T>
+static int slab_analysis_runs_impl(ndwt_plan* p, int Lp, const void* in, void* const* out, long long n_planes, long long n_runs,
+                                   long long run_stride, hipStream_t s) {
+    const long long plane = p->vol / p->dims[2];
+    const T* ins[8] = {(const T*)in};
+    return fused3_run<T>(p, false, Lp, ins, (T* const*)out, n_planes, n_runs, run_stride * plane, run_stride * plane, 0, s);
+}
+
+// run r: planes [e0 + r*e_stride, +n_out) of the zero-extended synthesis of n_in coefficient planes -> out + r*n_out planes
+template <typename T>
+static int slab_synthesis_runs_impl(ndwt_plan* p, int Lp, const void* const* in, long long n_in, long long e0, long long e_stride,
+                                    long long n_runs, long long n_out, void* out, hipStream_t s) {
+    const long long plane = p->vol / p->dims[2];
+    const T* ins[8];
+    for (int b = 0; b < 8; ++b) ins[b] = (const T*)in[b] + e0 * plane;      // never dereferenced outside [0, n_in)
+    T* outs[8] = {(T*)out};
+    return fused3_run<T>(p, true, Lp, ins, outs, n_out, n_runs, e_stride * plane, n_out * plane, 3, s, -e0, n_in - e0, e_stride);
+}
 
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" {
@@ -883,6 +915,54 @@ int ndwt_synthesis_level_slab_ext(ndwt_plan* p, const void* const* in_local, voi
     HIP_TRY(hipSetDevice(p->device));
     return p->dtype == NDWT_F32 ? slab_ext_impl<float>(p, Lp, in_local, out_ext, (hipStream_t)stream)
                                 : slab_ext_impl<double>(p, Lp, in_local, out_ext, (hipStream_t)stream);
+}
+
+int ndwt_analysis_level_slab_part(ndwt_plan* p, const void* in_local, const void* halo_before, const void* halo_after,
+                                  void* const* out, int stride, int64_t n_planes, void* stream) {
+    int Lp = 0;
+    int rc = slab_fast_ok(p, stride, &Lp);
+    if (rc) return rc;
+    if (!in_local || !out || (Lp > 2 && !halo_before) || !halo_after) return fail(NDWT_ERR_INVALID_ARG, "null pointer");
+    if (n_planes < 1 || n_planes > INT32_MAX) return fail(NDWT_ERR_INVALID_ARG, "n_planes must be >= 1");
+    HIP_TRY(hipSetDevice(p->device));
+    if (!halo_before) halo_before = halo_after;
+    return p->dtype == NDWT_F32
+               ? slab_analysis_part_impl<float>(p, Lp, in_local, halo_before, halo_after, out, n_planes, (hipStream_t)stream)
+               : slab_analysis_part_impl<double>(p, Lp, in_local, halo_before, halo_after, out, n_planes, (hipStream_t)stream);
+}
+
+int ndwt_synthesis_level_slab_runs(ndwt_plan* p, const void* const* in_local, int64_t n_in, int64_t e0, int64_t e_stride,
+                                   int64_t n_runs, int64_t n_out, void* out, int stride, void* stream) {
+    int Lp = 0;
+    int rc = slab_fast_ok(p, stride, &Lp);
+    if (rc) return rc;
+    if (!in_local || !out) return fail(NDWT_ERR_INVALID_ARG, "null pointer");
+    if (n_in < 1 || e0 < 0 || n_out < 1 || n_runs < 1 || e_stride < 0 || n_in > INT32_MAX ||
+        e0 + (n_runs - 1) * e_stride + n_out > n_in + Lp - 1)
+        return fail(NDWT_ERR_INVALID_ARG, "every run of output planes must lie inside the %lld planes of the zero-extended result",
+                    (long long)(n_in + Lp - 1));
+    HIP_TRY(hipSetDevice(p->device));
+    return p->dtype == NDWT_F32
+               ? slab_synthesis_runs_impl<float>(p, Lp, in_local, n_in, e0, e_stride, n_runs, n_out, out, (hipStream_t)stream)
+               : slab_synthesis_runs_impl<double>(p, Lp, in_local, n_in, e0, e_stride, n_runs, n_out, out, (hipStream_t)stream);
+}
+
+int ndwt_synthesis_level_slab_part(ndwt_plan* p, const void* const* in_local, int64_t n_in, int64_t e0, int64_t n_out,
+                                   void* out, int stride, void* stream) {
+    return ndwt_synthesis_level_slab_runs(p, in_local, n_in, e0, 0, 1, n_out, out, stride, stream);
+}
+
+int ndwt_analysis_level_slab_runs(ndwt_plan* p, const void* in_with_halo, void* const* out, int stride, int64_t n_planes,
+                                  int64_t n_runs, int64_t run_stride, void* stream) {
+    int Lp = 0;
+    int rc = slab_fast_ok(p, stride, &Lp);
+    if (rc) return rc;
+    if (!in_with_halo || !out) return fail(NDWT_ERR_INVALID_ARG, "null pointer");
+    if (n_planes < 1 || n_planes > INT32_MAX || n_runs < 1 || run_stride < 0) return fail(NDWT_ERR_INVALID_ARG, "bad run geometry");
+    HIP_TRY(hipSetDevice(p->device));
+    return p->dtype == NDWT_F32
+               ? slab_analysis_runs_impl<float>(p, Lp, in_with_halo, out, n_planes, n_runs, run_stride, (hipStream_t)stream)
+               : slab_analysis_runs_impl<double>(p, Lp, in_with_halo, out, n_planes, n_runs, run_stride, (hipStream_t)stream);
 }
 
 const char* ndwt_last_error(void) { return g_last_error.c_str(); }

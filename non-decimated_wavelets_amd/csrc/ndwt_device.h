@@ -143,7 +143,10 @@ template <typename T> struct Fused3Args {
     int ntx, nty, nzc;     // tiles per axis
     int z_wrap;            // outer axis: 1 periodic; 0 inputs start `left` planes before local plane 0 (haloed slab);
                            // 2 analysis with separate halo buffers in[1] (before) / in[2] (after); 3 synthesis of the
-                           // zero-extended slab: n3 = n_in + L-1 output planes, inputs outside the slab read as 0
+                           // zero-extended slab: output plane k sums input planes k-(L-1)..k, planes outside
+                           // [zlo, zhi) read as 0 (whole slab: zlo = 0, zhi = n_in, n3 = n_in + L-1)
+    int zlo, zhi;          // z_wrap == 3 only
+    int zbs;               // z_wrap == 3: batch item i tests plane + i*zbs against [zlo, zhi) (runs of one slab)
     int dbg;               // timing experiments only (wrong results): bit0 = fold halo reads back into the tile
 };
 
@@ -512,11 +515,11 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
     }
 
     // issue the global loads of (plane zraw, y-bit yb) into st.pre
-    static NDWT_DEV void load_raw(State& st, const Args& a, long long ibase, int zraw, int yb, int tid) {
+    static NDWT_DEV void load_raw(State& st, const Args& a, long long ibase, int zraw, int yb, int tid, int zsh) {
         long long zm = a.z_wrap == 1 ? (long long)modn(zraw, a.n3) : (long long)(zraw + LH);
         if (a.z_wrap == 3) {                             // zero-extended slab: output plane k needs inputs k-(L-1)+j
             zm = zraw - RH;
-            if (zm < 0 || zm >= a.n3 - (L - 1)) {
+            if (zm + zsh < a.zlo || zm + zsh >= a.zhi) {
                 NDWT_SFOR(k, NLI)
                     st.pre[k][0] = (v4)(T(0));
                     st.pre[k][1] = (v4)(T(0));
@@ -646,11 +649,12 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
         const TileCoord tc = decode_tile(a, bid, TX, TY);
         const long long ibase = (long long)tc.batch * a.in_bstride;
         const long long obase = (long long)tc.batch * a.out_bstride;
+        const int zsh = tc.batch * a.zbs;
         const int nsteps = tc.zend - tc.zbeg;
         const int nplanes = nsteps + L - 1;              // planes zbeg-LH .. zend-1+RH
         ex.each([&](int tid, State& st) __attribute__((always_inline)) {
             setup(st, a, tc, tid);
-            load_raw(st, a, ibase, tc.zbeg - LH, 0, tid);
+            load_raw(st, a, ibase, tc.zbeg - LH, 0, tid, zsh);
         });
         for (int p = 0; p < nplanes; ++p) {
             const int zraw = tc.zbeg - LH + p;
@@ -658,8 +662,8 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
             for (int yb = 0; yb < 2; ++yb) {
                 ex.each([&](int tid, State& st) __attribute__((always_inline)) {
                     stash_raw(st, sh, tid);
-                    if (yb == 0) load_raw(st, a, ibase, zraw, 1, tid);
-                    else if (p + 1 < nplanes) load_raw(st, a, ibase, zraw + 1, 0, tid);
+                    if (yb == 0) load_raw(st, a, ibase, zraw, 1, tid, zsh);
+                    else if (p + 1 < nplanes) load_raw(st, a, ibase, zraw + 1, 0, tid, zsh);
                 });
                 ex.barrier();
                 ex.each([&](int tid, State&) __attribute__((always_inline)) { xsyn(sh, tp, yb, tid); });
@@ -771,11 +775,11 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
         NDWT_SEND
     }
 
-    static NDWT_DEV void load_raw(State& st, const Args& a, long long ibase, int zraw) {
+    static NDWT_DEV void load_raw(State& st, const Args& a, long long ibase, int zraw, int zsh) {
         long long zm = a.z_wrap == 1 ? (long long)modn(zraw, a.n3) : (long long)(zraw + LH);
         if (a.z_wrap == 3) {                             // zero-extended slab
             zm = zraw - RH;
-            if (zm < 0 || zm >= a.n3 - (L - 1)) {
+            if (zm + zsh < a.zlo || zm + zsh >= a.zhi) {
                 NDWT_SFOR(k, NRND)
                     NDWT_SFOR(b, 8)
                         st.raw[k][b] = (v4)(T(0));
@@ -901,17 +905,18 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
         const TileCoord tc = decode_tile(a, bid, TX, TY);
         const long long ibase = (long long)tc.batch * a.in_bstride;
         const long long obase = (long long)tc.batch * a.out_bstride;
+        const int zsh = tc.batch * a.zbs;
         const int nsteps = tc.zend - tc.zbeg;
         const int nplanes = nsteps + L - 1;              // planes zbeg-LH .. zend-1+RH
         ex.each([&](int tid, State& st) __attribute__((always_inline)) {
             setup(st, a, tc, tid);
-            load_raw(st, a, ibase, tc.zbeg - LH);
+            load_raw(st, a, ibase, tc.zbeg - LH, zsh);
         });
         for (int p = 0; p < nplanes; ++p) {
             const int s = p - (L - 1);
             ex.each([&](int tid, State& st) __attribute__((always_inline)) { xsyn(ex, st, sh, tp, p & 1, tid); });
             ex.each([&](int, State& st) __attribute__((always_inline)) {                 // (separate pass only matters to the host emulator)
-                if (p + 1 < nplanes) load_raw(st, a, ibase, tc.zbeg - LH + p + 1);
+                if (p + 1 < nplanes) load_raw(st, a, ibase, tc.zbeg - LH + p + 1, zsh);
             });
             ex.barrier();
             ex.each([&](int tid, State& st) __attribute__((always_inline)) {

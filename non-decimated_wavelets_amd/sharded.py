@@ -67,10 +67,46 @@ class HipSlabEngine:
     def synthesis_ext(self, ins_local, out_ext, stride):
         self.plan.synthesis_level_slab_ext([t.data_ptr() for t in ins_local], out_ext.data_ptr(), stride, self._stream())
 
+    # runs of planes (ndwt_*_slab_part): the pieces the exchange overlaps with.  Pointers are computed from the base
+    # addresses (no tensor views: this runs once per piece per level on the host's critical path).
+    def analysis_run(self, cur, hb, ha, outs, z0, z1, stride):
+        """output planes [z0, z1) of the slab's analysis level.  The planes around the run come from the slab itself,
+        or -- for a run that starts at plane 0 / ends at the last plane -- from the received halo buffers hb / ha."""
+        ab, aa, _, _ = self.halo(stride)
+        n, pb = cur.shape[0], cur.stride(0) * cur.element_size()
+        base = cur.data_ptr()
+        assert (z0 == 0 or z0 >= ab) and (z1 == n or z1 + aa <= n)
+        before = (hb.data_ptr() if ab else None) if z0 == 0 else base + (z0 - ab) * pb
+        after = ha.data_ptr() if z1 == n else base + z1 * pb
+        self.plan.analysis_level_slab_part(base + z0 * pb, before, after, [o.data_ptr() + z0 * pb for o in outs], z1 - z0,
+                                           stride, self._stream())
+
+    def analysis_ends(self, slab_buf, outs, stride):
+        """the first and the last max(ab, aa) output planes in ONE launch.  slab_buf: [halo_before | slab | halo_after]
+        contiguous, (ab + n + aa) planes, the halo planes received in place."""
+        ab, aa, _, _ = self.halo(stride)
+        n, m = slab_buf.shape[0] - ab - aa, max(ab, aa)
+        self.plan.analysis_level_slab_runs(slab_buf.data_ptr(), [o.data_ptr() for o in outs], m, 2, n - m, stride, self._stream())
+
+    def synthesis_part(self, ins_local, e0, out_run, stride):
+        """planes [e0, e0 + len(out_run)) of the zero-extended synthesis of the local coefficient slab"""
+        self.plan.synthesis_level_slab_part([t.data_ptr() for t in ins_local], ins_local[0].shape[0], e0, out_run.shape[0],
+                                            out_run.data_ptr(), stride, self._stream())
+
+    def synthesis_send_parts(self, ins_local, stride):
+        """(part_before, part_after): the partial sums owed to the slabs ahead (sa planes) and behind (sb planes), both
+        from ONE launch (two runs of max(sa, sb) planes at the two ends of the zero-extended result)."""
+        _, _, sb, sa = self.halo(stride)
+        n, m = ins_local[0].shape[0], max(sa, sb)
+        buf = ins_local[0].new_empty((2, m) + tuple(ins_local[0].shape[1:]))
+        self.plan.synthesis_level_slab_runs([t.data_ptr() for t in ins_local], n, 0, n + sa + sb - m, 2, m, buf.data_ptr(), stride,
+                                            self._stream())
+        return buf[0, :sa], buf[1, m - sb:]
+
 
 class ShardedNdDwt:
     def __init__(self, wname, sizes, pres_l2_norm=False, precision="double", dilation="reference", group=None, device=None,
-                 engine=None, synthesis_scheme="auto"):
+                 engine=None, synthesis_scheme="auto", overlap=True):
         self.sizes = [int(s) for s in sizes]
         self.d = len(self.sizes)
         self.wname = [wname] * self.d if isinstance(wname, str) else list(wname)
@@ -96,6 +132,9 @@ class ShardedNdDwt:
         self.scheme = synthesis_scheme
         self.nb = 1 << self.d
         self._exchange_cache = {}
+        # overlap of the exchange with the planes that do not depend on it needs the run-of-planes entry points
+        self.overlap = bool(overlap and self.scheme == "scatter" and hasattr(self.engine, "analysis_run")
+                            and hasattr(self.engine, "synthesis_part"))
 
     # ---------------------------------------------------------------------------------- plumbing
     def _owner(self, g):
@@ -125,18 +164,29 @@ class ShardedNdDwt:
         self._exchange_cache[key] = segs
         return segs
 
-    def _run_p2p(self, ops):
-        if not ops:
-            return
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-
     def _fetch_halo(self, t, ax, before, after):
         """t: local tensor whose dim `ax` (0 or 1) is the sharded axis.  Returns (halo_before, halo_after).
         Segments are contiguous plane ranges: with ax == 0 they are sent / received in place (no staging copies)."""
+        hb, ha, pending = self._start_fetch_halo(t, ax, before, after)
+        self._finish_exchange(pending)
+        return hb, ha
+
+    def _finish_exchange(self, pending):
+        works, post, _keep = pending
+        for w in works:
+            w.wait()
+        for fn in post:
+            fn()
+
+    def _start_fetch_halo(self, t, ax, before, after, hb=None, ha=None):
+        """Posts the exchange and returns (halo_before, halo_after, pending); the halos are valid after
+        _finish_exchange(pending).  Work that does not read them may be issued in between.  hb / ha: optional
+        destination buffers (the margins of a [halo | slab | halo] buffer)."""
         shp = list(t.shape)
-        hb = t.new_empty(shp[:ax] + [before] + shp[ax + 1:])
-        ha = t.new_empty(shp[:ax] + [after] + shp[ax + 1:])
+        if hb is None:
+            hb = t.new_empty(shp[:ax] + [before] + shp[ax + 1:])
+        if ha is None:
+            ha = t.new_empty(shp[:ax] + [after] + shp[ax + 1:])
         ops, keep, post = [], [], []
         for q, side, p, k0, l0, n in self._plan_exchange(before, after):
             if p != self.rank and q != self.rank:
@@ -155,34 +205,45 @@ class ShardedNdDwt:
                 else:
                     buf = torch.empty(dst.shape, dtype=dst.dtype, device=dst.device)
                     ops.append(dist.P2POp(dist.irecv, buf, self._global_rank(p), self.group))
-                    post.append((dst, buf))
-        self._run_p2p(ops)
-        for dst, buf in post:
-            dst.copy_(buf)
-        return hb, ha
+                    post.append(lambda dst=dst, buf=buf: dst.copy_(buf))
+        works = dist.batch_isend_irecv(ops) if ops else []
+        return hb, ha, (works, post, keep)
 
     def _scatter_add(self, ext, before, after):
         """ext: (before + n_local + after, ...) partial sums; planes outside the slab go to their owners and are added.
         Returns the completed local slab (a view of ext)."""
-        ops, post = [], []
         own = ext.narrow(0, before, self.n_local)
-        local_adds = []
+        pending = self._start_scatter(ext.narrow(0, 0, before), ext.narrow(0, before + self.n_local, after), before, after)
+        self._finish_scatter(pending, own)
+        return own
+
+    def _start_scatter(self, part_before, part_after, before, after):
+        """Posts the sends of the partial planes this rank owes (part_before: for the `before` planes ahead of its
+        slab, part_after: for the `after` planes behind it) and the receives of what it is owed."""
+        ops, adds_local, adds_recv = [], [], []
+        parts = (part_before, part_after)
         # rank q PRODUCES partial planes for the global planes around its slab; the owner p ADDS them
         for q, side, p, k0, l0, n in self._plan_exchange(before, after):
             if q == self.rank:
-                part = ext.narrow(0, k0 if side == 0 else before + self.n_local + k0, n)   # contiguous view
+                part = parts[side].narrow(0, k0, n)                 # contiguous view
                 if p == self.rank:
-                    local_adds.append((l0, n, part))
+                    adds_local.append((l0, n, part))
                 else:
                     ops.append(dist.P2POp(dist.isend, part, self._global_rank(p), self.group))
             elif p == self.rank:
-                buf = torch.empty([n] + list(ext.shape[1:]), dtype=ext.dtype, device=ext.device)
+                ref = parts[side]
+                buf = torch.empty([n] + list(ref.shape[1:]), dtype=ref.dtype, device=ref.device)
                 ops.append(dist.P2POp(dist.irecv, buf, self._global_rank(q), self.group))
-                post.append((l0, n, buf))
-        self._run_p2p(ops)
-        for l0, n, buf in local_adds + post:
+                adds_recv.append((l0, n, buf))
+        works = dist.batch_isend_irecv(ops) if ops else []
+        return works, adds_local + adds_recv, parts
+
+    def _finish_scatter(self, pending, own):
+        works, adds, _keep = pending
+        for w in works:
+            w.wait()
+        for l0, n, buf in adds:
             own.narrow(0, l0, n).add_(buf)
-        return own
 
     def _global_rank(self, r):
         return r if self.group is None or self.group is dist.group.WORLD else dist.get_global_rank(self.group, r)
@@ -196,24 +257,51 @@ class ShardedNdDwt:
         nb, nbt = self.nb, self.nb + (self.nb - 1) * (level - 1)
         x_local = x_local.to(self.dtype).contiguous()
         y = x_local.new_empty((nbt,) + tuple(x_local.shape))
-        cur = x_local
+        cur, cur_buf = x_local, None          # cur_buf: [halo | cur | halo] buffer when cur was produced with margins
         spare = [None, None]
+        n, inner = self.n_local, tuple(x_local.shape[1:])
         for lev in range(1, level + 1):
             s = self._stride(lev)
             ab, aa, _, _ = self.engine.halo(s)
+            overlap = self.overlap and n > ab + aa
+            a_buf = None
             if lev == level:
                 a_out = y[0]
+            elif overlap and hasattr(self.engine, "analysis_ends"):
+                # the next level's input is produced inside a buffer with room for its halo planes on both sides
+                ab2, aa2 = self.engine.halo(self._stride(lev + 1))[:2]
+                k = (lev - 1) & 1
+                if spare[k] is None or spare[k].shape[0] != ab2 + n + aa2:
+                    spare[k] = x_local.new_empty((ab2 + n + aa2,) + inner)
+                a_buf = spare[k]
+                a_out = a_buf[ab2:ab2 + n]
             else:
-                if spare[(lev - 1) & 1] is None:
-                    spare[(lev - 1) & 1] = torch.empty_like(x_local)
-                a_out = spare[(lev - 1) & 1]
+                k = (lev - 1) & 1
+                if spare[k] is None or spare[k].shape[0] != n:
+                    spare[k] = torch.empty_like(x_local)
+                a_out = spare[k]
             outs = [a_out] + [y[1 + (nb - 1) * (level - lev) + (b - 1)] for b in range(1, nb)]
-            hb, ha = self._fetch_halo(cur, 0, ab, aa)
-            if hasattr(self.engine, "analysis_split") and getattr(self.engine, "supports_scatter", False):
-                self.engine.analysis_split(cur, hb, ha, outs, s)
+            if overlap:
+                # interior planes [ab, n-aa) read the slab only: run them while the halo planes travel
+                if cur_buf is not None:
+                    hb, ha, pending = self._start_fetch_halo(cur, 0, ab, aa, cur_buf[:ab], cur_buf[ab + n:])
+                else:
+                    hb, ha, pending = self._start_fetch_halo(cur, 0, ab, aa)
+                self.engine.analysis_run(cur, hb, ha, outs, ab, n - aa, s)
+                self._finish_exchange(pending)
+                if cur_buf is not None:
+                    self.engine.analysis_ends(cur_buf, outs, s)           # both ends, one launch
+                else:
+                    if ab:
+                        self.engine.analysis_run(cur, hb, ha, outs, 0, ab, s)
+                    self.engine.analysis_run(cur, hb, ha, outs, n - aa, n, s)
             else:
-                self.engine.analysis(torch.cat([hb, cur, ha], 0), outs, s)
-            cur = a_out
+                hb, ha = self._fetch_halo(cur, 0, ab, aa)
+                if hasattr(self.engine, "analysis_split") and getattr(self.engine, "supports_scatter", False):
+                    self.engine.analysis_split(cur, hb, ha, outs, s)
+                else:
+                    self.engine.analysis(torch.cat([hb, cur, ha], 0), outs, s)
+            cur, cur_buf = a_out, a_buf
         return y
 
     def rec(self, y):
@@ -227,7 +315,23 @@ class ShardedNdDwt:
             s = self._stride(lev)
             _, _, sb, sa = self.engine.halo(s)
             ins = [prev] + [y[1 + (nb - 1) * (level - lev) + (b - 1)] for b in range(1, nb)]
-            if self.scheme == "scatter":
+            if self.scheme == "scatter" and self.overlap:
+                # the partial sums owed to the neighbours first (sa planes ahead of the slab, sb behind it: they depend
+                # on the first / last coefficient planes only), then the slab's own planes while those travel
+                n, inner = self.n_local, tuple(prev.shape[1:])
+                if hasattr(self.engine, "synthesis_send_parts"):
+                    part_b, part_a = self.engine.synthesis_send_parts(ins, s)
+                else:
+                    part_b, part_a = prev.new_empty((sa,) + inner), prev.new_empty((sb,) + inner)
+                    if sa:
+                        self.engine.synthesis_part(ins, 0, part_b, s)
+                    self.engine.synthesis_part(ins, sa + n, part_a, s)
+                pending = self._start_scatter(part_b, part_a, sa, sb)
+                own = prev.new_empty((n,) + inner)
+                self.engine.synthesis_part(ins, sa, own, s)
+                self._finish_scatter(pending, own)
+                prev = own
+            elif self.scheme == "scatter":
                 # zero-extended synthesis: partial sums for sa planes before and sb planes after the slab
                 ext = prev.new_empty((sa + self.n_local + sb,) + tuple(prev.shape[1:]))
                 self.engine.synthesis_ext(ins, ext, s)

@@ -79,6 +79,8 @@ int emu3(int inverse, int Lp, int vec4, const T* in, T* out, int n1, int n2, int
     const int halo = Lp - 1;
     const long long vol_in = z_wrap ? vol : (long long)n1 * n2 * (n3 + halo);
     a.z_wrap = z_wrap;
+    a.zlo = 0;
+    a.zhi = n3 - (Lp - 1);
     if (!inverse) {
         a.in[0] = in;
         for (int b = 0; b < 8; ++b) a.out[b] = out + b * vol * nbatch;

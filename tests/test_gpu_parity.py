@@ -325,17 +325,43 @@ def test_copy_free_slab_entry_points_and_sharded_driver_on_one_gpu():
             slab.synthesis_level_slab_ext([yl[b].data_ptr() for b in range(8)], ext.data_ptr(), 1)
             idx = torch.arange(z0 - sa, z1 + sb, device="cuda") % n3
             r_acc.index_add_(0, idx, ext)                              # what the scatter-add exchange does
+            # runs of planes of the same two calls (what the exchange overlaps with): bit-identical pieces
+            o2 = torch.full_like(outs, float("nan"))
+            for a0, a1, before, after in ((ab, nl - aa, loc[:ab], loc[nl - aa:]), (0, ab, hb, loc[ab:ab + aa]),
+                                          (nl - aa, nl, loc[nl - aa - ab:nl - aa], ha)):
+                slab.analysis_level_slab_part(loc[a0:a1].data_ptr(), before.data_ptr(), after.data_ptr(),
+                                              [o2[b, a0:a1].data_ptr() for b in range(8)], a1 - a0, 1)
+            assert torch.equal(o2, outs)
+            e2 = torch.full_like(ext, float("nan"))
+            for e0, e1 in ((0, sa), (sa + nl, sa + nl + sb), (sa, sa + nl)):
+                slab.synthesis_level_slab_part([yl[b].data_ptr() for b in range(8)], nl, e0, e1 - e0, e2[e0:e1].data_ptr(), 1)
+            assert float((e2 - ext).abs().max()) <= 1e-6 * float(ext.abs().max())
+            # both ends in one launch: [halo | slab | halo] contiguous input, two runs of max(ab, aa) planes
+            m = max(ab, aa)
+            buf = torch.cat([hb, loc, ha], 0)
+            o3 = torch.full_like(outs, float("nan"))
+            slab.analysis_level_slab_runs(buf.data_ptr(), [o3[b].data_ptr() for b in range(8)], m, 2, nl - m, 1)
+            assert torch.equal(o3[:, :m], outs[:, :m]) and torch.equal(o3[:, nl - m:], outs[:, nl - m:])
+            assert bool(torch.isnan(o3[:, m:nl - m]).all())
+            e3 = torch.full((2, sb) + tuple(ext.shape[1:]), float("nan"), device="cuda", dtype=dtype)
+            slab.synthesis_level_slab_runs([yl[b].data_ptr() for b in range(8)], nl, 0, nl + sa, 2, sb, e3.data_ptr(), 1)
+            assert float((e3[0, :sa] - ext[:sa]).abs().max()) <= 1e-6 * float(ext.abs().max())
+            assert float((e3[1] - ext[sa + nl:]).abs().max()) <= 1e-6 * float(ext.abs().max())
+            with pytest.raises(ndwt.NdwtError, match="zero-extended"):
+                slab.synthesis_level_slab_part([yl[b].data_ptr() for b in range(8)], nl, nl, 8, e2.data_ptr(), 1)
         torch.cuda.synchronize()
         assert float((r_acc - x).abs().max()) <= 20 * tol * float(x.abs().max())
     # the driver itself with world size 1 (halo planes come from the own slab)
-    eng = sh.ShardedNdDwt(["db4"] * 3, [n1, n2, n3], pres_l2_norm=True, precision="single", device=torch.device("cuda", 0))
-    assert eng.scheme == "scatter"
     xs = torch.randn(n3, n2, n1, device="cuda")
     w = ndwt.nd_dwt_3D("db4", [n1, n2, n3], "pres_l2_norm", 1, "precision", "single")
     yref = w.dec(xs.permute(2, 1, 0), 3).permute(3, 2, 1, 0)
-    ysh = eng.dec(xs, 3)
-    assert float((ysh - yref).abs().max()) <= 2e-6 * float(yref.abs().max())
-    assert float((eng.rec(ysh) - xs).abs().max()) <= 1e-5
+    for overlap in (True, False):
+        eng = sh.ShardedNdDwt(["db4"] * 3, [n1, n2, n3], pres_l2_norm=True, precision="single", device=torch.device("cuda", 0),
+                              overlap=overlap)
+        assert eng.scheme == "scatter" and eng.overlap == overlap
+        ysh = eng.dec(xs, 3)
+        assert float((ysh - yref).abs().max()) <= 2e-6 * float(yref.abs().max())
+        assert float((eng.rec(ysh) - xs).abs().max()) <= 1e-5
 
 
 def test_fused2d_kernels_at_baseline_config2_shape():

@@ -65,6 +65,34 @@ class OracleSlabEngine:
         out_ext.copy_(r[pad - sa: pad + n + sb])
 
 
+    def analysis_run(self, cur, hb, ha, outs, z0, z1, stride):
+        ab, aa, _, _ = self.halo(stride)
+        n = cur.shape[0]
+        assert (z0 == 0 or z0 >= ab) and (z1 == n or z1 + aa <= n)
+        before = hb if z0 == 0 else cur[z0 - ab:z0]
+        after = ha if z1 == n else cur[z1:z1 + aa]
+        self.analysis(torch.cat([before, cur[z0:z1], after], 0), [o[z0:z1] for o in outs], stride)
+
+    def analysis_ends(self, slab_buf, outs, stride):
+        ab, aa, _, _ = self.halo(stride)
+        n, m = slab_buf.shape[0] - ab - aa, max(ab, aa)
+        for z0 in (0, n - m):
+            self.analysis(slab_buf[z0:z0 + ab + m + aa], [o[z0:z0 + m] for o in outs], stride)
+
+    def synthesis_send_parts(self, ins_local, stride):
+        _, _, sb, sa = self.halo(stride)
+        n = ins_local[0].shape[0]
+        ext = ins_local[0].new_empty((sa + n + sb,) + tuple(ins_local[0].shape[1:]))
+        self.synthesis_ext(ins_local, ext, stride)
+        return ext[:sa].clone(), ext[sa + n:].clone()
+
+    def synthesis_part(self, ins_local, e0, out_run, stride):
+        _, _, sb, sa = self.halo(stride)
+        ext = ins_local[0].new_empty((sa + ins_local[0].shape[0] + sb,) + tuple(ins_local[0].shape[1:]))
+        self.synthesis_ext(ins_local, ext, stride)
+        out_run.copy_(ext[e0:e0 + out_run.shape[0]])
+
+
 def _worker(rank, world, port, sizes, wname, level, l2, dilation, scheme, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -77,20 +105,24 @@ def _worker(rank, world, port, sizes, wname, level, l2, dilation, scheme, q):
         sh = importlib.import_module("non-decimated_wavelets_amd.sharded")
         rng = np.random.default_rng(7)
         x = rng.standard_normal(sizes)                         # MATLAB shape, same on every rank
-        eng = sh.ShardedNdDwt(wname, sizes, pres_l2_norm=l2, precision="double", dilation=dilation,
-                              engine=OracleSlabEngine(wname, l2), synthesis_scheme=scheme)
         xk = torch.from_numpy(np.ascontiguousarray(np.transpose(x)))
-        y_loc = eng.dec(xk[eng.z0:eng.z1].contiguous(), level)
         want = np.ascontiguousarray(np.transpose(orc.spatial_dec(x, wname, level, l2, dilation)))   # (bands, n_d, ..., n1)
-        e_dec = float(np.abs(y_loc.numpy() - want[:, eng.z0:eng.z1]).max())
-        r_loc = eng.rec(y_loc)
-        e_rec = float(np.abs(r_loc.numpy() - xk[eng.z0:eng.z1].numpy()).max())
-        # rec of arbitrary coefficients (not in the range of dec)
         c = rng.standard_normal(list(sizes) + [orc.num_bands(len(sizes), level)])
         ck = torch.from_numpy(np.ascontiguousarray(np.transpose(c)))
-        r2 = eng.rec(ck[:, eng.z0:eng.z1].contiguous())
         want2 = np.ascontiguousarray(np.transpose(orc.spatial_rec(c, wname, l2, dilation)))
-        e_rec2 = float(np.abs(r2.numpy() - want2[eng.z0:eng.z1]).max())
+        e_dec = e_rec = e_rec2 = 0.0
+        # the scatter scheme runs twice: exchange overlapped with the interior planes (default), and one piece
+        for overlap in ((True, False) if scheme == "scatter" else (False,)):
+            eng = sh.ShardedNdDwt(wname, sizes, pres_l2_norm=l2, precision="double", dilation=dilation,
+                                  engine=OracleSlabEngine(wname, l2), synthesis_scheme=scheme, overlap=overlap)
+            assert eng.overlap == overlap
+            y_loc = eng.dec(xk[eng.z0:eng.z1].contiguous(), level)
+            e_dec = max(e_dec, float(np.abs(y_loc.numpy() - want[:, eng.z0:eng.z1]).max()))
+            r_loc = eng.rec(y_loc)
+            e_rec = max(e_rec, float(np.abs(r_loc.numpy() - xk[eng.z0:eng.z1].numpy()).max()))
+            # rec of arbitrary coefficients (not in the range of dec)
+            r2 = eng.rec(ck[:, eng.z0:eng.z1].contiguous())
+            e_rec2 = max(e_rec2, float(np.abs(r2.numpy() - want2[eng.z0:eng.z1]).max()))
         q.put((rank, e_dec, e_rec, e_rec2))
     finally:
         dist.destroy_process_group()
