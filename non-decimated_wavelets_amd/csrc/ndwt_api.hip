@@ -263,6 +263,7 @@ static bool fused3_eligible(const ndwt_plan* p, long long stride, int* Lp_out) {
     int Lp = 2;
     for (int a = 0; a < 3; ++a) Lp = p->filt[a].len > Lp ? p->filt[a].len : Lp;
     if (Lp > 12) return false;   // instantiated tap lengths: 2..12 (db1..db6); longer filters take the per-axis path
+    if (p->dtype == NDWT_F64 && Lp > 10) return false;   // double, db6: the fused kernels spill (6.7 ms vs 4.8 ms per-axis at 256^3)
     // interleaved complex: fused float kernels with the x taps stepping over (re, im) pairs, tap lengths <= 8
     if (p->complexity != NDWT_REAL && (p->dtype != NDWT_F32 || Lp > 8 || (p->dims[0] * 2) % 4 != 0)) return false;
     long long nbatch = p->ndim == 4 ? p->dims[3] + 64 : 1;
@@ -311,6 +312,8 @@ void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int
     *TY = f64 ? 8 : 16;
     if (!f64 && inverse && !((variant == 2 || variant == 3) && Lp == 8)) *TY = 32;   // float synthesis default: tall tile
     if (!f64 && !inverse && variant == 2 && (Lp == 8 || Lp == 12)) *TY = 32;
+    if (f64 && !inverse && Lp >= 10) *TY = 16;                                         // double analysis, db5/db6: 512 threads
+    if (f64 && inverse && !(variant == 3 && Lp == 8)) *TY = 16;                        // double synthesis default: lane-shift kernel, 64x16
 }
 }  // namespace ndwt
 
@@ -643,7 +646,7 @@ int ndwt_plan_create(ndwt_plan** plan, int ndim, const int64_t* dims, const char
     p->comp = complexity == NDWT_COMPLEX_INTERLEAVED ? 2 : 1;
     p->target_blocks = 2048;
     p->prof = new std::vector<ProfRec>();
-    p->fp64_fused = 0;   // measured: 256^3 fp64 db4 L3 3.8 ms per-axis (march + lane-shift kernels) vs 5.2 ms fused (LDS synthesis kernel)
+    p->fp64_fused = 1;   // measured: 256^3 fp64 db4 L3 2.5 ms fused (LDS analysis + lane-shift synthesis) vs 4.1 ms per-axis
     if (const char* v = getenv("NDWT_FP64_FUSED")) p->fp64_fused = atoi(v);
     if (const char* v = getenv("NDWT_VARIANT_FWD")) p->variant_fwd = atoi(v);
     if (const char* v = getenv("NDWT_VARIANT_INV")) p->variant_inv = atoi(v);

@@ -3,6 +3,14 @@
 namespace ndwt {
 int launch_fwd3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4, int variant, int ew, const void* taps_dev, hipStream_t s) {
     if (ew != 1) return -1;
-    NDWT_FUSED_SWITCH(Fwd3, Fwd3, false, double)
+    switch (t.Lp) {
+        NDWT_FUSED_CASE(Fwd3, false, double, 2, 0)
+        NDWT_FUSED_CASE(Fwd3, false, double, 4, 0)
+        NDWT_FUSED_CASE(Fwd3, false, double, 6, 0)
+        NDWT_FUSED_CASE(Fwd3, false, double, 8, 0)
+        NDWT_FUSED_CASE(Fwd3, false, double, 10, 1)
+        NDWT_FUSED_CASE(Fwd3, false, double, 12, 1)
+        default: return -1;
+    }
 }
 }  // namespace ndwt

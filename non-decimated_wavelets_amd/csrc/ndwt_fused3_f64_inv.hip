@@ -3,6 +3,6 @@
 namespace ndwt {
 int launch_inv3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4, int variant, int ew, const void* taps_dev, hipStream_t s) {
     if (ew != 1) return -1;
-    NDWT_FUSED_SWITCH(Inv3, Inv3S, true, double)
+    NDWT_FUSED_SWITCH_INV_F64(double)
 }
 }  // namespace ndwt

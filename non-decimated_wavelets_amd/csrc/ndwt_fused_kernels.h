@@ -118,6 +118,19 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
         default: return -1;                                               \
     }
 
+// double synthesis: the lane-shift kernel on a 64x16 tile with 512 threads; variant 3 = the LDS kernel (A/B runs, db4 only)
+#define NDWT_FUSED_SWITCH_INV_F64(T)                                      \
+    if (variant == 3 && t.Lp == 8) { switch (t.Lp) { NDWT_FUSED_CASE(Inv3, true, T, 8, 3) } }   \
+    switch (t.Lp) {                                                       \
+        NDWT_FUSED_CASE(Inv3S, true, T, 2, 1)                             \
+        NDWT_FUSED_CASE(Inv3S, true, T, 4, 1)                             \
+        NDWT_FUSED_CASE(Inv3S, true, T, 6, 1)                             \
+        NDWT_FUSED_CASE(Inv3S, true, T, 8, 1)                             \
+        NDWT_FUSED_CASE(Inv3S, true, T, 10, 1)                            \
+        NDWT_FUSED_CASE(Inv3S, true, T, 12, 1)                            \
+        default: return -1;                                               \
+    }
+
 // float analysis: 256-thread kernel for tap lengths <= 8, 512 threads (one column per thread) for 10 and 12;
 // variant 2 = tall 64x32 tile with 1024 threads (A/B runs)
 #define NDWT_FUSED_SWITCH_FWD_F32(T)                                      \

@@ -18,5 +18,7 @@ template <> struct Fused3Tile<float, true, 2>  { static constexpr int TX = 64, T
 template <> struct Fused3Tile<float, true, 3>  { static constexpr int TX = 64, TY = 16, NT = 256, RY = 2, WPE = 2; };   // LDS kernel (Inv3), for A/B runs
 // double
 template <int V> struct Fused3Tile<double, false, V> { static constexpr int TX = 64, TY = 8, NT = 256, RY = 4, WPE = 2; };
+template <> struct Fused3Tile<double, false, 1>      { static constexpr int TX = 64, TY = 16, NT = 512, RY = 4, WPE = 2; };   // long filters (db5, db6)
 template <int V> struct Fused3Tile<double, true, V>  { static constexpr int TX = 64, TY = 8, NT = 256, RY = 4, WPE = 2; };
+template <> struct Fused3Tile<double, true, 1>       { static constexpr int TX = 64, TY = 16, NT = 512, RY = 2, WPE = 2; };   // lane-shift kernel (Inv3S): the double default
 }  // namespace ndwt
