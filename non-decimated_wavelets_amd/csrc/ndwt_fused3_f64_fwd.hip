@@ -2,7 +2,16 @@
 #include "ndwt_fused_kernels.h"
 namespace ndwt {
 int launch_fwd3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4, int variant, int ew, const void* taps_dev, hipStream_t s) {
-    if (ew != 1) return -1;
+    if (ew != 1 && ew != 2) return -1;
+    if (ew == 2) {
+        switch (t.Lp) {
+            NDWT_FUSED_CASE_C(Fwd3, false, double, 2, 0)
+            NDWT_FUSED_CASE_C(Fwd3, false, double, 4, 0)
+            NDWT_FUSED_CASE_C(Fwd3, false, double, 6, 0)
+            NDWT_FUSED_CASE_C(Fwd3, false, double, 8, 0)
+            default: return -1;
+        }
+    }
     switch (t.Lp) {
         NDWT_FUSED_CASE(Fwd3, false, double, 2, 0)
         NDWT_FUSED_CASE(Fwd3, false, double, 4, 0)

@@ -120,6 +120,15 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
 
 // double synthesis: the lane-shift kernel on a 64x16 tile with 512 threads; variant 3 = the LDS kernel (A/B runs, db4 only)
 #define NDWT_FUSED_SWITCH_INV_F64(T)                                      \
+    if (ew == 2) {                                                        \
+        switch (t.Lp) {                                                   \
+            NDWT_FUSED_CASE_C(Inv3S, true, T, 2, 1)                       \
+            NDWT_FUSED_CASE_C(Inv3S, true, T, 4, 1)                       \
+            NDWT_FUSED_CASE_C(Inv3S, true, T, 6, 1)                       \
+            NDWT_FUSED_CASE_C(Inv3S, true, T, 8, 1)                       \
+            default: return -1;                                           \
+        }                                                                 \
+    }                                                                     \
     if (variant == 3 && t.Lp == 8) { switch (t.Lp) { NDWT_FUSED_CASE(Inv3, true, T, 8, 3) } }   \
     switch (t.Lp) {                                                       \
         NDWT_FUSED_CASE(Inv3S, true, T, 2, 1)                             \

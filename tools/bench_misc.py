@@ -38,5 +38,6 @@ def run(name, dims, dtype, cplx, dilation, level=3, K=5):
 
 run("3D complex64 256^3 db4 L3 (reference test input type)", [256, 256, 256], torch.float32, True, "reference")
 run("3D fp64 256^3 db4 L3", [256, 256, 256], torch.float64, False, "reference")
+run("3D complex128 256^3 db4 L3 (reference test input type, mex precision)", [256, 256, 256], torch.float64, True, "reference")
 run("3D fp32 256^3 db4 L3 a-trous", [256, 256, 256], torch.float32, False, "atrous")
 run("3D fp32 256^3 db4 L3", [256, 256, 256], torch.float32, False, "reference")
