@@ -75,7 +75,7 @@ struct ndwt_plan {
     void* approx[2];                   // approximation ping-pong between levels
     void* tmp;                         // temporaries of the per-axis path / 4-D split
     size_t tmp_bytes;
-    int target_blocks;                 // fused-kernel grid sizing
+    int target_blocks;                 // fused-kernel grid sizing: 0 = one round of resident workgroups (per kernel), else as given
     int force_zchunk;
     int zchunk_dir[2];                 // per-direction override of the marched chunk: [0] analysis, [1] synthesis (0 = auto)
     int variant_fwd, variant_inv;      // fused-kernel variants (tuning experiments; same results)
@@ -342,9 +342,12 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     const int variant = inverse ? p->variant_inv : p->variant_fwd;
     fused3_tile_shape(sizeof(T) == 8, inverse, variant, Lp, &TX, &TY);
     const int zc_force = p->zchunk_dir[inverse ? 1 : 0] > 0 ? p->zchunk_dir[inverse ? 1 : 0] : p->force_zchunk;
-    // the 1024-thread synthesis kernel runs one workgroup per CU: aim at one wave of workgroups over the chip
-    const bool tall = TY == 32 && inverse;
-    const int target = (tall && p->target_blocks == 2048) ? p->num_cus : p->target_blocks;
+    // One round of workgroups that all fit on the chip at once beats several partial rounds (measured, 512^3 float
+    // analysis: 512 workgroups 0.88 ms, 1024: 1.09 ms, 2048: 0.99 ms; 256^3 double synthesis: 256 workgroups 0.36 ms,
+    // 640: 0.48 ms).  Workgroups per CU: synthesis 1 (1024 threads / 94 KB of LDS), analysis 2 (3 fit, 2 run faster).
+    const bool small_inv = inverse && sizeof(T) == 4 && (variant == 2 || variant == 3) && Lp == 8;   // 256-thread A/B variants
+    const int per_cu = inverse ? (small_inv ? 3 : 1) : 2;
+    const int target = p->target_blocks > 0 ? p->target_blocks : p->num_cus * per_cu;
     fused3_geometry(a, TX, TY, Lp, target, zc_force);
     FusedTapsD t = fused_taps(p, Lp, inverse);
     const void* td = p->taps_dev[inverse ? 1 : 0];
@@ -388,7 +391,7 @@ static int fused2_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     const int nin = inverse ? 4 : 1, nout = inverse ? 1 : 4;
     for (int b = 0; b < nin; ++b) { a.in[b] = in[b]; vec4 = vec4 && aligned_vec4<T>(in[b]); }
     for (int b = 0; b < nout; ++b) { a.out[b] = out[b]; vec4 = vec4 && aligned_vec4<T>(out[b]); }
-    fused2_geometry(a, fused2_tile_width(inverse, Lp, (int)p->comp), Lp, p->target_blocks * 2, p->force_zchunk);
+    fused2_geometry(a, fused2_tile_width(inverse, Lp, (int)p->comp), Lp, p->target_blocks > 0 ? p->target_blocks * 2 : 4096, p->force_zchunk);
     const void* td = p->taps_dev[inverse ? 1 : 0];
     if (!td) return fail(NDWT_ERR_UNSUPPORTED, "plan has no device tap table");
     prof_begin(p, inverse ? NDWT_KERNEL_FUSED_SYNTHESIS : NDWT_KERNEL_FUSED_ANALYSIS, s);
@@ -644,7 +647,7 @@ int ndwt_plan_create(ndwt_plan** plan, int ndim, const int64_t* dims, const char
     p->path = NDWT_PATH_AUTO;
     p->esize = dtype == NDWT_F32 ? 4 : 8;
     p->comp = complexity == NDWT_COMPLEX_INTERLEAVED ? 2 : 1;
-    p->target_blocks = 2048;
+    p->target_blocks = 0;
     p->prof = new std::vector<ProfRec>();
     p->fp64_fused = 1;   // measured: 256^3 fp64 db4 L3 2.5 ms fused (LDS analysis + lane-shift synthesis) vs 4.1 ms per-axis
     if (const char* v = getenv("NDWT_FP64_FUSED")) p->fp64_fused = atoi(v);
@@ -766,7 +769,7 @@ int ndwt_plan_set_path(ndwt_plan* p, int path) {
 // test/tuning hook: grid sizing of the fused kernels (0 = default)
 int ndwt_plan_set_tuning(ndwt_plan* p, int target_blocks, int force_zchunk) {
     if (!p) return fail(NDWT_ERR_INVALID_ARG, "null plan");
-    p->target_blocks = target_blocks > 0 ? target_blocks : 2048;
+    p->target_blocks = target_blocks > 0 ? target_blocks : 0;
     p->force_zchunk = force_zchunk > 0 ? force_zchunk : 0;
     return NDWT_OK;
 }

@@ -7,15 +7,16 @@
 namespace ndwt {
 
 // fills the tiling fields of `a` (n1,n2,n3,nbatch must be set).  Workgroups march `zchunk` output
-// planes each; the chunk is sized so the grid has at least ~target_blocks workgroups (>> 256 CUs)
-// while the (L-1)-plane march prologue stays a small fraction of the chunk.
+// planes each; the chunk is sized so the grid has at most ~target_blocks workgroups (the number that is
+// resident on the chip at once: one full round, no partial second round) while the (L-1)-plane march
+// prologue stays a small fraction of the chunk.
 template <typename T>
 inline void fused3_geometry(Fused3Args<T>& a, int TX, int TY, int Lp, int target_blocks = 2048, int force_zchunk = 0) {
     a.ntx = (a.n1 + TX - 1) / TX;
     a.nty = (a.n2 + TY - 1) / TY;
     a.plane = (long long)a.n1 * a.n2;
     long long per_chunk = (long long)a.ntx * a.nty * a.nbatch;
-    int want = (int)((target_blocks + per_chunk - 1) / per_chunk);
+    int want = (int)(target_blocks / per_chunk);
     if (want < 1) want = 1;
     int zc = (a.n3 + want - 1) / want;
     int min_chunk = 4 * (Lp - 1);                 // prologue <= 25 % of the chunk
