@@ -69,8 +69,10 @@ int dispatch(int Lp, int vec4, ndwt::Fused3Args<T>& a, const double* lo, const d
 #undef CASE
 }
 
-template <typename T>
-int emu3(int inverse, int Lp, int vec4, const T* in, T* out, int n1, int n2, int n3, int nbatch, int zchunk,
+// INV is a compile-time parameter so that the analysis and synthesis kernels land in separate translation units
+// (tests/emu/Makefile compiles this file once per EMU_PART, in parallel)
+template <typename T, bool INV>
+int emu3(int Lp, int vec4, const T* in, T* out, int n1, int n2, int n3, int nbatch, int zchunk,
          const double* lo, const double* hi, int z_wrap, int small_tile, int variant, int ew) {
     ndwt::Fused3Args<T> a;
     std::memset(&a, 0, sizeof(a));
@@ -81,52 +83,63 @@ int emu3(int inverse, int Lp, int vec4, const T* in, T* out, int n1, int n2, int
     a.z_wrap = z_wrap;
     a.zlo = 0;
     a.zhi = n3 - (Lp - 1);
-    if (!inverse) {
+    a.in_bstride = vol_in; a.out_bstride = vol;
+    if constexpr (!INV) {
         a.in[0] = in;
         for (int b = 0; b < 8; ++b) a.out[b] = out + b * vol * nbatch;
-        a.in_bstride = vol_in; a.out_bstride = vol;
     } else {
         for (int b = 0; b < 8; ++b) a.in[b] = in + b * vol_in * nbatch;
         a.out[0] = out;
-        a.in_bstride = vol_in; a.out_bstride = vol;
     }
-    if (ew == 2) {      // interleaved complex: n1 counts scalars; lane-shift synthesis and LDS analysis kernels
-        if (small_tile) {
-            ndwt::fused3_geometry(a, 16, 8, Lp, 2048, zchunk);
-            return inverse ? dispatch<T, ndwt::Inv3S, 16, 8, 128, 2, true, 2>(Lp, vec4, a, lo, hi)
-                           : dispatch<T, ndwt::Fwd3, 16, 8, 64, 2, true, 2>(Lp, vec4, a, lo, hi);
-        }
-        typedef ndwt::Fused3Tile<T, false, 0> QF;
-        typedef ndwt::Fused3Tile<T, true, 1> QI;
-        if (inverse) {
-            ndwt::fused3_geometry(a, QI::TX, QI::TY, Lp, 2048, zchunk);
-            return dispatch<T, ndwt::Inv3S, QI::TX, QI::TY, QI::NT, QI::RY, false, 2>(Lp, vec4, a, lo, hi);
-        }
-        ndwt::fused3_geometry(a, QF::TX, QF::TY, Lp, 2048, zchunk);
-        return dispatch<T, ndwt::Fwd3, QF::TX, QF::TY, QF::NT, QF::RY, false, 2>(Lp, vec4, a, lo, hi);
-    }
-    if (small_tile) {   // a second tile shape exercises different item/lane mappings
-        ndwt::fused3_geometry(a, 16, 8, Lp, 2048, zchunk);
-        if (variant == 2 && inverse)   // lane-shift synthesis on the small tile, every tap length
-            return dispatch<T, ndwt::Inv3S, 16, 8, 128, 2, true>(Lp, vec4, a, lo, hi);
-        return inverse ? dispatch<T, ndwt::Inv3, 16, 8, 64, 2, true>(Lp, vec4, a, lo, hi)
-                       : dispatch<T, ndwt::Fwd3, 16, 8, 64, 2, true>(Lp, vec4, a, lo, hi);
-    }
-    // the tile shapes the library launches (variant `small_tile`-2... 0 = default)
+    // the tile shapes the library launches
     typedef ndwt::Fused3Tile<T, false, 0> PF;
     typedef ndwt::Fused3Tile<T, true, 0> PI;
     typedef ndwt::Fused3Tile<T, false, 1> PF1;
-    typedef ndwt::Fused3Tile<T, true, 1> PI1;
-    typedef ndwt::Fused3Tile<T, true, 2> PI2;   // float: the default lane-shift synthesis configuration
-    ndwt::fused3_geometry(a, PF::TX, PF::TY, Lp, 2048, zchunk);
-    if (variant == 1 && inverse) ndwt::fused3_geometry(a, PI1::TX, PI1::TY, Lp, 2048, zchunk);
-    if (variant == 3 && inverse)
-        return dispatch<T, ndwt::Inv3S, PI2::TX, PI2::TY, PI2::NT, PI2::RY, false>(Lp, vec4, a, lo, hi);
-    if (variant == 1)
-        return inverse ? dispatch<T, ndwt::Inv3S, PI1::TX, PI1::TY, PI1::NT, PI1::RY, false>(Lp, vec4, a, lo, hi)
-                       : dispatch<T, ndwt::Fwd3, PF1::TX, PF1::TY, PF1::NT, PF1::RY, false>(Lp, vec4, a, lo, hi);
-    return inverse ? dispatch<T, ndwt::Inv3, PI::TX, PI::TY, PI::NT, PI::RY, false>(Lp, vec4, a, lo, hi)
-                   : dispatch<T, ndwt::Fwd3, PF::TX, PF::TY, PF::NT, PF::RY, false>(Lp, vec4, a, lo, hi);
+    typedef ndwt::Fused3Tile<T, true, 1> PI1;   // the default lane-shift synthesis configuration (float and double)
+    typedef ndwt::Fused3Tile<T, true, 2> PI2;   // lane-shift synthesis, smaller tile
+    if (ew == 2) {      // interleaved complex: n1 counts scalars; lane-shift synthesis and LDS analysis kernels
+        if (small_tile) {
+            ndwt::fused3_geometry(a, 16, 8, Lp, 2048, zchunk);
+            if constexpr (INV) return dispatch<T, ndwt::Inv3S, 16, 8, 128, 2, true, 2>(Lp, vec4, a, lo, hi);
+            else return dispatch<T, ndwt::Fwd3, 16, 8, 64, 2, true, 2>(Lp, vec4, a, lo, hi);
+        }
+        if constexpr (INV) {
+            ndwt::fused3_geometry(a, PI1::TX, PI1::TY, Lp, 2048, zchunk);
+            return dispatch<T, ndwt::Inv3S, PI1::TX, PI1::TY, PI1::NT, PI1::RY, false, 2>(Lp, vec4, a, lo, hi);
+        } else {
+            ndwt::fused3_geometry(a, PF::TX, PF::TY, Lp, 2048, zchunk);
+            return dispatch<T, ndwt::Fwd3, PF::TX, PF::TY, PF::NT, PF::RY, false, 2>(Lp, vec4, a, lo, hi);
+        }
+    }
+    if (small_tile) {   // a second tile shape exercises different item/lane mappings
+        ndwt::fused3_geometry(a, 16, 8, Lp, 2048, zchunk);
+        if constexpr (INV) {
+            if (variant == 2)   // lane-shift synthesis on the small tile, every tap length
+                return dispatch<T, ndwt::Inv3S, 16, 8, 128, 2, true>(Lp, vec4, a, lo, hi);
+            return dispatch<T, ndwt::Inv3, 16, 8, 64, 2, true>(Lp, vec4, a, lo, hi);
+        } else {
+            return dispatch<T, ndwt::Fwd3, 16, 8, 64, 2, true>(Lp, vec4, a, lo, hi);
+        }
+    }
+    if constexpr (INV) {
+        if (variant == 3) {
+            ndwt::fused3_geometry(a, PI2::TX, PI2::TY, Lp, 2048, zchunk);
+            return dispatch<T, ndwt::Inv3S, PI2::TX, PI2::TY, PI2::NT, PI2::RY, false>(Lp, vec4, a, lo, hi);
+        }
+        if (variant == 1) {
+            ndwt::fused3_geometry(a, PI1::TX, PI1::TY, Lp, 2048, zchunk);
+            return dispatch<T, ndwt::Inv3S, PI1::TX, PI1::TY, PI1::NT, PI1::RY, false>(Lp, vec4, a, lo, hi);
+        }
+        ndwt::fused3_geometry(a, PI::TX, PI::TY, Lp, 2048, zchunk);
+        return dispatch<T, ndwt::Inv3, PI::TX, PI::TY, PI::NT, PI::RY, false>(Lp, vec4, a, lo, hi);
+    } else {
+        if (variant == 1) {
+            ndwt::fused3_geometry(a, PF1::TX, PF1::TY, Lp, 2048, zchunk);
+            return dispatch<T, ndwt::Fwd3, PF1::TX, PF1::TY, PF1::NT, PF1::RY, false>(Lp, vec4, a, lo, hi);
+        }
+        ndwt::fused3_geometry(a, PF::TX, PF::TY, Lp, 2048, zchunk);
+        return dispatch<T, ndwt::Fwd3, PF::TX, PF::TY, PF::NT, PF::RY, false>(Lp, vec4, a, lo, hi);
+    }
 }
 
 template <class K, typename T> int run2(ndwt::Fused2Args<T>& a, const double* lo, const double* hi) {
@@ -268,7 +281,16 @@ int emu_axisx(int syn, int L, int ew, int vec4, const T* in0, const T* in1, T* o
 
 }  // namespace
 
+// Each EMU_PART is one translation unit of libndwt_emu*.so (parallel build); without EMU_PART everything is compiled.
+#ifndef EMU_PART
+#define EMU_ALL 1
+#else
+#define EMU_ALL 0
+#endif
+#define EMU_IN(part) (EMU_ALL || EMU_PART == part)
+
 extern "C" {
+#if EMU_IN(1)
 int ndwt_emu_axisx_f32(int syn, int L, int ew, int vec4, const float* in0, const float* in1, float* out0, float* out1, long long row,
                        long long outer, const double* lo, const double* hi) {
     return emu_axisx<float>(syn, L, ew, vec4, in0, in1, out0, out1, row, outer, lo, hi);
@@ -277,6 +299,8 @@ int ndwt_emu_axisx_f64(int syn, int L, int ew, int vec4, const double* in0, cons
                        long long outer, const double* lo, const double* hi) {
     return emu_axisx<double>(syn, L, ew, vec4, in0, in1, out0, out1, row, outer, lo, hi);
 }
+#endif
+#if EMU_IN(2)
 int ndwt_emu_march_f32(int syn, int L, const float* in0, const float* in1, float* out0, float* out1, long long inner, long long n,
                        long long outer, int chunk, int wrap, const double* lo, const double* hi) {
     return emu_march<float>(syn, L, in0, in1, out0, out1, inner, n, outer, chunk, wrap, lo, hi);
@@ -285,21 +309,41 @@ int ndwt_emu_march_f64(int syn, int L, const double* in0, const double* in1, dou
                        long long outer, int chunk, int wrap, const double* lo, const double* hi) {
     return emu_march<double>(syn, L, in0, in1, out0, out1, inner, n, outer, chunk, wrap, lo, hi);
 }
+#endif
+#if EMU_IN(3)
 int ndwt_emu2_f32(int inverse, int Lp, int vec4, const float* in, float* out, int n1, int n2, int ychunk, const double* lo,
                   const double* hi, int y_wrap, int ew) {
     return emu2<float>(inverse, Lp, vec4, in, out, n1, n2, ychunk, lo, hi, y_wrap, ew);
 }
+#endif
+#if EMU_IN(4)
 int ndwt_emu2_f64(int inverse, int Lp, int vec4, const double* in, double* out, int n1, int n2, int ychunk, const double* lo,
                   const double* hi, int y_wrap, int ew) {
     return emu2<double>(inverse, Lp, vec4, in, out, n1, n2, ychunk, lo, hi, y_wrap, ew);
 }
+#endif
 // in/out: band-planar, batch inside band: [band][batch][n3(+halo)][n2][n1]; lo/hi: [3][20] padded kernel-form taps
-int ndwt_emu3_f32(int inverse, int Lp, int vec4, const float* in, float* out, int n1, int n2, int n3, int nbatch,
-                  int zchunk, const double* lo, const double* hi, int z_wrap, int small_tile, int variant, int ew) {
-    return emu3<float>(inverse, Lp, vec4, in, out, n1, n2, n3, nbatch, zchunk, lo, hi, z_wrap, small_tile, variant, ew);
-}
-int ndwt_emu3_f64(int inverse, int Lp, int vec4, const double* in, double* out, int n1, int n2, int n3, int nbatch,
-                  int zchunk, const double* lo, const double* hi, int z_wrap, int small_tile, int variant, int ew) {
-    return emu3<double>(inverse, Lp, vec4, in, out, n1, n2, n3, nbatch, zchunk, lo, hi, z_wrap, small_tile, variant, ew);
-}
+#define EMU3_ARGS(T) int Lp, int vec4, const T* in, T* out, int n1, int n2, int n3, int nbatch, int zchunk, const double* lo, \
+                     const double* hi, int z_wrap, int small_tile, int variant, int ew
+#define EMU3_PASS Lp, vec4, in, out, n1, n2, n3, nbatch, zchunk, lo, hi, z_wrap, small_tile, variant, ew
+#if EMU_IN(5)
+int ndwt_emu3_f32_fwd(EMU3_ARGS(float)) { return emu3<float, false>(EMU3_PASS); }
+#endif
+#if EMU_IN(6)
+int ndwt_emu3_f32_inv(EMU3_ARGS(float)) { return emu3<float, true>(EMU3_PASS); }
+#endif
+#if EMU_IN(7)
+int ndwt_emu3_f64_fwd(EMU3_ARGS(double)) { return emu3<double, false>(EMU3_PASS); }
+#endif
+#if EMU_IN(8)
+int ndwt_emu3_f64_inv(EMU3_ARGS(double)) { return emu3<double, true>(EMU3_PASS); }
+#endif
+#if EMU_IN(1)
+int ndwt_emu3_f32_fwd(EMU3_ARGS(float));
+int ndwt_emu3_f32_inv(EMU3_ARGS(float));
+int ndwt_emu3_f64_fwd(EMU3_ARGS(double));
+int ndwt_emu3_f64_inv(EMU3_ARGS(double));
+int ndwt_emu3_f32(int inverse, EMU3_ARGS(float)) { return inverse ? ndwt_emu3_f32_inv(EMU3_PASS) : ndwt_emu3_f32_fwd(EMU3_PASS); }
+int ndwt_emu3_f64(int inverse, EMU3_ARGS(double)) { return inverse ? ndwt_emu3_f64_inv(EMU3_PASS) : ndwt_emu3_f64_fwd(EMU3_PASS); }
+#endif
 }

@@ -25,7 +25,7 @@ def emu():
     # with the ASan runtime preloaded (tests/emu/run_emu_tests.sh) use the sanitizer build, else the plain one
     asan = "libclang_rt.asan" in os.environ.get("LD_PRELOAD", "")
     target = "libndwt_emu.so" if asan else "libndwt_emu_plain.so"
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), target])
+    subprocess.check_call(["make", "-s", "-j", str(min(8, os.cpu_count() or 1)), "-C", os.path.join(ROOT, "tests", "emu"), target])
     return ctypes.CDLL(os.path.join(ROOT, "tests", "emu", target))
 
 
@@ -93,7 +93,8 @@ def test_emulated_fused3_synthesis(emu, sizes, wn, vec4, zchunk, small, l2):
     for dtype, tol in ((np.float64, 1e-13), (np.float32, 2e-6)):
         # variants 1 (production tile, float) and 2 (small tile, every tap length) are the lane-shift synthesis kernel
         # 3: the library's default float synthesis configuration (lane-shift kernel, 64x16 tile, 256 threads)
-        for variant in ((0, 1, 3) if not small and dtype == np.float32 else (0, 2) if small else (0,)):
+        # double: 1 = the library's default synthesis configuration (lane-shift kernel, 64x16 tile, 512 threads)
+        for variant in ((0, 1, 3) if not small and dtype == np.float32 else (0, 2) if small else (0, 1)):
             got = _run(emu, c, wn, l2, True, dtype, vec4, zchunk, small, variant=variant)
             assert np.isfinite(got).all()
             assert np.abs(got - want).max() <= tol * max(np.abs(want).max(), 1.0)
