@@ -810,24 +810,40 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
             bool valid;
             lane_item(tid, k, ug, r, valid);
             NDWT_SFOR(yb, 2)
-                v2 acc[4];
-                acc[0] = acc[1] = acc[2] = acc[3] = (v2)(T(0));
+                // Scalar accumulators per z-bit: the loaded registers feed the FMAs as they are.  (Accumulating (z-bit 0,
+                // z-bit 1) pairs makes hipcc build the pairs with v_mov right behind the loads -- i.e. wait for the
+                // next plane's loads before the barrier instead of leaving them in flight across the y/z stage;
+                // packed FMAs have no rate advantage on CDNA4.  The translation unit is built with -fno-slp-vectorize
+                // for the same reason: the SLP vectorizer would re-pack these.)
+                T a0[4], a1[4];
+                NDWT_SFOR(e, 4)
+                    a0[e] = T(0);
+                    a1[e] = T(0);
+                NDWT_SEND
                 NDWT_SFOR(i, XV)                          // window element i <-> x offset i - 4*GL from this lane's first x
                     constexpr int D = i / 4 - GL;         // lane distance
                     constexpr int c = i % 4;
-                    // (z-bit 0, z-bit 1) of the low-pass (x-bit 0) and high-pass (x-bit 1) inputs
-                    v2 wa = {NDWT_LANE_SHIFT(ex, tid, D, s.raw[k][0 + 2 * yb][c]), NDWT_LANE_SHIFT(ex, tid, D, s.raw[k][4 + 2 * yb][c])};
-                    v2 wd = {NDWT_LANE_SHIFT(ex, tid, D, s.raw[k][1 + 2 * yb][c]), NDWT_LANE_SHIFT(ex, tid, D, s.raw[k][5 + 2 * yb][c])};
+                    // low-pass (x-bit 0) and high-pass (x-bit 1) inputs of z-bit 0 and z-bit 1
+                    const T wa0 = NDWT_LANE_SHIFT(ex, tid, D, s.raw[k][0 + 2 * yb][c]);
+                    const T wd0 = NDWT_LANE_SHIFT(ex, tid, D, s.raw[k][1 + 2 * yb][c]);
+                    const T wa1 = NDWT_LANE_SHIFT(ex, tid, D, s.raw[k][4 + 2 * yb][c]);
+                    const T wd1 = NDWT_LANE_SHIFT(ex, tid, D, s.raw[k][5 + 2 * yb][c]);
                     NDWT_SFOR(e, 4)
                         constexpr int dj = i - 4 * GL - e;                 // = (j - LH) * EW
                         if constexpr (dj % EW == 0) {
                             constexpr int j = dj / EW + LH;
                             if constexpr (j >= 0 && j < L) {
-                                acc[e] += tp.lo[0][j] * wa;
-                                acc[e] += tp.hi[0][j] * wd;
+                                a0[e] += tp.lo[0][j] * wa0;
+                                a0[e] += tp.hi[0][j] * wd0;
+                                a1[e] += tp.lo[0][j] * wa1;
+                                a1[e] += tp.hi[0][j] * wd1;
                             }
                         }
                     NDWT_SEND
+                NDWT_SEND
+                v2 acc[4];
+                NDWT_SFOR(e, 4)
+                    acc[e] = v2{a0[e], a1[e]};
                 NDWT_SEND
                 if (valid && ug >= GL && ug < GL + TX / 4) lds_store_run<T, 4>(sh.xs[buf][yb][r], 4 * (ug - GL), acc);
             NDWT_SEND
@@ -1123,23 +1139,28 @@ template <typename T, int L_, bool VEC4_, int WPE_ = 4, int EW_ = 1> struct Inv2
     template <int R, class Exec>
     static NDWT_DEV void step(Exec& ex, State& st, const Taps& tp, const Args& a, const Tile2Coord& tc, long long obase, int y,
                               bool emit, int tid) {
-        v2 P[4];           // (a, d) of the y-synthesis = x-synthesis of (y-bit 0, y-bit 1)
-        NDWT_SFOR(e, 4)
-            P[e] = (v2)(T(0));
+        T p0[4], p1[4];    // x-synthesis of y-bit 0 / y-bit 1 = the (a, d) inputs of the y-synthesis; scalars, not pairs:
+        NDWT_SFOR(e, 4)    // see Inv3S::xsyn (pairs would be built right behind the prefetch loads)
+            p0[e] = T(0);
+            p1[e] = T(0);
         NDWT_SEND
         NDWT_SFOR(i, XV)
             constexpr int D = i / 4 - GL;
             constexpr int c = i % 4;
             {
-                v2 wa = {NDWT_LANE_SHIFT(ex, tid, D, s.raw[0][c]), NDWT_LANE_SHIFT(ex, tid, D, s.raw[2][c])};   // x-bit 0
-                v2 wd = {NDWT_LANE_SHIFT(ex, tid, D, s.raw[1][c]), NDWT_LANE_SHIFT(ex, tid, D, s.raw[3][c])};   // x-bit 1
+                const T wa0 = NDWT_LANE_SHIFT(ex, tid, D, s.raw[0][c]);   // x-bit 0, y-bit 0
+                const T wd0 = NDWT_LANE_SHIFT(ex, tid, D, s.raw[1][c]);   // x-bit 1, y-bit 0
+                const T wa1 = NDWT_LANE_SHIFT(ex, tid, D, s.raw[2][c]);   // x-bit 0, y-bit 1
+                const T wd1 = NDWT_LANE_SHIFT(ex, tid, D, s.raw[3][c]);   // x-bit 1, y-bit 1
                 NDWT_SFOR(e, 4)
                     constexpr int dj = i - 4 * GL - e;
                     if constexpr (dj % EW == 0) {
                         constexpr int j = dj / EW + LH;
                         if constexpr (j >= 0 && j < L) {
-                            P[e] += tp.lo[0][j] * wa;
-                            P[e] += tp.hi[0][j] * wd;
+                            p0[e] += tp.lo[0][j] * wa0;
+                            p0[e] += tp.hi[0][j] * wd0;
+                            p1[e] += tp.lo[0][j] * wa1;
+                            p1[e] += tp.hi[0][j] * wd1;
                         }
                     }
                 NDWT_SEND
@@ -1148,7 +1169,7 @@ template <typename T, int L_, bool VEC4_, int WPE_ = 4, int EW_ = 1> struct Inv2
         NDWT_SFOR(j, L)
             constexpr int slot = ((R - 1 - j) % L + L) % L;
             NDWT_SFOR(e, 4)
-                const T c = tp.lo[1][j] * P[e].x + tp.hi[1][j] * P[e].y;
+                const T c = tp.lo[1][j] * p0[e] + tp.hi[1][j] * p1[e];
                 if constexpr (j == 0) st.yacc[slot][e] = c;
                 else st.yacc[slot][e] += c;
             NDWT_SEND
