@@ -30,4 +30,8 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
 print(json.dumps({"config": f"4D fp32 {dims} db4 L3", "path": plan.describe(), "ms_per_step": round(dt * 1e3, 3), "Mvox_s": round(V / dt / 1e6, 1),
                   "roofline_frac": round(2 * level * 17 * V * 4 / dt / 8e12, 4),
-                  "rt": float(torch.linalg.vector_norm((r - x).double()) / torch.linalg.vector_norm(x.double()))}))
+                  "rt": float(torch.linalg.vector_norm((r - x).double()) / torch.linalg.vector_norm(x.double())),
+                  # pres_l2_norm: the coefficient energy equals the signal energy (a band left unwritten would show here)
+                  "energy_ratio": float(sum(float(torch.linalg.vector_norm(y[b].double())) ** 2 for b in range(nb)) ** 0.5
+                                        / float(torch.linalg.vector_norm(x.double()))),
+                  "coefficient_GiB": round(nb * V * 4 / 2 ** 30, 1)}))
