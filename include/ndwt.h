@@ -99,6 +99,17 @@ int ndwt_rec(ndwt_plan* plan, const void* y_dev, void* x_dev, int level, void* s
 int ndwt_dec_host(ndwt_plan* plan, const void* x_host, void* y_host, int level);
 int ndwt_rec_host(ndwt_plan* plan, const void* y_host, void* x_host, int level);
 
+/* ---- consumers for iterative solvers (extension; the reference's users threshold the bands in MATLAB, README.md:2) ----
+ * ndwt_shrink: in-place soft / hard thresholding of every detail band of a level-`level` coefficient array (band 0, the
+ *   coarsest approximation, is kept); complex data: the magnitude is shrunk, the phase kept.
+ * ndwt_denoise: dec -> shrink -> rec in one call; the coefficients live in a scratch array owned by the plan, so only
+ *   the signal crosses the boundary (x and out may be the same buffer).  The host form moves 2 x prod(dims) elements
+ *   over PCIe instead of 2 x prod(dims) x bands. */
+enum { NDWT_SHRINK_SOFT = 0, NDWT_SHRINK_HARD = 1 };
+int ndwt_shrink(ndwt_plan* plan, void* y_dev, int level, double threshold, int mode, void* stream);
+int ndwt_denoise(ndwt_plan* plan, const void* x_dev, void* out_dev, int level, double threshold, int mode, void* stream);
+int ndwt_denoise_host(ndwt_plan* plan, const void* x_host, void* out_host, int level, double threshold, int mode);
+
 /* Split complex: separate real / imaginary arrays, the layout the reference's gateway receives from MATLAB
  * (mxGetPr / mxGetPi, nd_dwt_mex.c:55-58,90-93) and hands to nd_dwt_dec / nd_dwt_rec (outR/outI, imageR/imageI,
  * nddwt.h:13-20).  The plan must be NDWT_REAL (real filters: each part is transformed on its own); the imaginary

@@ -83,6 +83,17 @@ class Plan:
     def rec(self, y_ptr, x_ptr, level, stream=0):
         L.check(L.lib().ndwt_rec(self._h, y_ptr, x_ptr, int(level), ctypes.c_void_p(stream)))
 
+    def shrink(self, y_ptr, level, threshold, hard=False, stream=0):
+        """in-place soft (default) / hard thresholding of the detail bands"""
+        L.check(L.lib().ndwt_shrink(self._h, y_ptr, int(level), float(threshold), int(bool(hard)), ctypes.c_void_p(stream)))
+
+    def denoise(self, x_ptr, out_ptr, level, threshold, hard=False, stream=0):
+        """dec -> shrink -> rec with the coefficients in a scratch array owned by the plan"""
+        L.check(L.lib().ndwt_denoise(self._h, x_ptr, out_ptr, int(level), float(threshold), int(bool(hard)), ctypes.c_void_p(stream)))
+
+    def denoise_host(self, x_ptr, out_ptr, level, threshold, hard=False):
+        L.check(L.lib().ndwt_denoise_host(self._h, x_ptr, out_ptr, int(level), float(threshold), int(bool(hard))))
+
     def dec_split(self, x_re, x_im, y_re, y_im, level, stream=0):
         """split complex (separate re / im device arrays, the mxGetPr / mxGetPi layout); x_im, y_im may be None"""
         L.check(L.lib().ndwt_dec_split(self._h, x_re, x_im, y_re, y_im, int(level), ctypes.c_void_p(stream)))
@@ -295,6 +306,44 @@ class _NdDwtBase:
         with torch.cuda.device(dev):
             plan.rec(yk.data_ptr(), xk.data_ptr(), level, _current_stream(dev))
         return self._from_device(xk, like_numpy, dev)
+
+    # -- consumers for iterative solvers (extension; not in the reference) --
+    def shrink(self, y, threshold, mode="soft"):
+        """Soft / hard thresholding of every detail band of a coefficient array (band 0, the coarsest approximation,
+        is kept); complex data: the magnitude is shrunk.  Returns a new array of the same kind as `y`."""
+        if mode not in ("soft", "hard"):
+            raise ValueError("mode must be 'soft' or 'hard'")
+        like_numpy = isinstance(y, np.ndarray)
+        if y.ndim != self.NDIM + 1 or list(y.shape[:-1]) != self.sizes:
+            raise ValueError(f"coefficient array must have shape {self.sizes + ['bands']}")
+        level = self._level_from_bands(int(y.shape[-1]))
+        dev = self._dev(y if isinstance(y, torch.Tensor) else None)
+        yk = self._to_device_kernel_order(y, dev, self.NDIM + 1)
+        if isinstance(y, torch.Tensor) and yk.data_ptr() == y.data_ptr():
+            yk = yk.clone()                                    # never modify the caller's array
+        plan = self._plan(yk.is_complex(), level, dev)
+        with torch.cuda.device(dev):
+            plan.shrink(yk.data_ptr(), level, threshold, mode == "hard", _current_stream(dev))
+        return self._from_device(yk, like_numpy, dev)
+
+    def denoise(self, x, level, threshold, mode="soft"):
+        """rec(shrink(dec(x, level), threshold)) in one call: the coefficients stay in a scratch array of the plan."""
+        if mode not in ("soft", "hard"):
+            raise ValueError("mode must be 'soft' or 'hard'")
+        level = int(level)
+        if level < 1:
+            raise ValueError("level must be >= 1")
+        like_numpy = isinstance(x, np.ndarray)
+        x = self._prep_dec_input(x)
+        if list(x.shape) != self.sizes:
+            raise ValueError(f"input size {list(x.shape)} does not match the object's sizes {self.sizes}")
+        dev = self._dev(x if isinstance(x, torch.Tensor) else None)
+        xk = self._to_device_kernel_order(x, dev, self.NDIM)
+        plan = self._plan(xk.is_complex(), level, dev)
+        out = torch.empty_like(xk)
+        with torch.cuda.device(dev):
+            plan.denoise(xk.data_ptr(), out.data_ptr(), level, threshold, mode == "hard", _current_stream(dev))
+        return self._from_device(out, like_numpy, dev)
 
     def _prep_dec_input(self, x):
         return x

@@ -82,6 +82,8 @@ struct ndwt_plan {
     int num_cus;
     int fp64_fused;                    // fp64: fused 3-D kernels (1) or the per-axis march kernels (0)
     void* taps_dev[2];                 // device tap tables of the fused kernels: [0] analysis, [1] synthesis (Taps3<T, Lp>)
+    void* coef;                        // coefficient scratch of ndwt_denoise (all bands of the last level used), lazily allocated
+    size_t coef_bytes;
     // optional per-kernel timing with HIP events on the launch stream (bench.py's roofline figures)
     int profiling;
     std::vector<ProfRec>* prof;
@@ -573,6 +575,64 @@ template <typename T> static int slab_ext_impl(ndwt_plan* p, int Lp, const void*
 }
 
 
+// --------------------------------------------------------------------------- shrinkage of detail bands
+// Element-wise, in place, 1 read + 1 write per coefficient (HBM-bound).  COMP = 2: interleaved complex, the magnitude
+// is shrunk and the phase kept.  mode 0 soft: c * max(|c| - t, 0) / |c|; mode 1 hard: c if |c| > t else 0.
+template <typename T, int COMP> __device__ __forceinline__ void shrink_group(T* c, T thr, int hard) {
+    if (COMP == 1) {
+        const T m = c[0] < T(0) ? -c[0] : c[0];
+        if (hard) c[0] = m > thr ? c[0] : T(0);
+        else c[0] = m > thr ? (c[0] < T(0) ? c[0] + thr : c[0] - thr) : T(0);
+    } else {
+        const T m = sqrt(c[0] * c[0] + c[1] * c[1]);
+        const T g = m > thr ? (hard ? T(1) : (m - thr) / m) : T(0);
+        c[0] *= g;
+        c[1] *= g;
+    }
+}
+
+// VEC: 4 scalars per thread and step (16-byte / 32-byte accesses; pointer aligned, n a multiple of 4); else one group
+template <typename T, int COMP, bool VEC>
+__global__ void __launch_bounds__(256) shrink_kernel(T* __restrict__ y, long long n_scalars, T thr, int hard) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (VEC) {
+        typedef typename VecT<T>::v4 v4;
+        v4* yv = reinterpret_cast<v4*>(y);
+        for (long long i = t0; i < n_scalars / 4; i += stride) {
+            v4 c = yv[i];
+            T e[4] = {c[0], c[1], c[2], c[3]};
+#pragma unroll
+            for (int k = 0; k < 4; k += COMP) shrink_group<T, COMP>(e + k, thr, hard);
+            yv[i] = v4{e[0], e[1], e[2], e[3]};
+        }
+    } else {
+        for (long long i = t0; i < n_scalars / COMP; i += stride) shrink_group<T, COMP>(y + i * COMP, thr, hard);
+    }
+}
+
+template <typename T> static int shrink_impl(ndwt_plan* p, T* y, int level, double thr, int mode, hipStream_t s) {
+    const long long nb = ndwt_num_bands(p->ndim, level);
+    T* d = y + p->vol;                                   // band 0 (coarsest approximation) is left as it is
+    const long long n = (nb - 1) * p->vol;
+    const bool vec = aligned_vec4<T>(d) && n % 4 == 0;
+    long long blocks = ((vec ? n / 4 : n / p->comp) + 255) / 256;
+    const long long cap = (long long)p->num_cus * 16;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    const dim3 g((unsigned)blocks), b(256);
+    if (p->comp == 2) {
+        if (vec) hipLaunchKernelGGL((shrink_kernel<T, 2, true>), g, b, 0, s, d, n, (T)thr, mode);
+        else hipLaunchKernelGGL((shrink_kernel<T, 2, false>), g, b, 0, s, d, n, (T)thr, mode);
+    } else {
+        if (vec) hipLaunchKernelGGL((shrink_kernel<T, 1, true>), g, b, 0, s, d, n, (T)thr, mode);
+        else hipLaunchKernelGGL((shrink_kernel<T, 1, false>), g, b, 0, s, d, n, (T)thr, mode);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(NDWT_ERR_HIP, "shrink kernel launch failed: %s", hipGetErrorString(e));
+    return NDWT_OK;
+}
+
 // a run of output planes of the slab transform (the caller offsets the pointers): what lets the halo exchange
 // overlap with the planes that do not depend on it
 template <typename T>
@@ -723,6 +783,7 @@ int ndwt_plan_destroy(ndwt_plan* p) {
     for (int i = 0; i < 2; ++i)
         if (p->approx[i]) (void)hipFree(p->approx[i]);
     if (p->tmp) (void)hipFree(p->tmp);
+    if (p->coef) (void)hipFree(p->coef);
     for (int i = 0; i < 2; ++i)
         if (p->taps_dev[i]) (void)hipFree(p->taps_dev[i]);
     if (p->prof) {
@@ -830,6 +891,66 @@ static int host_roundtrip(ndwt_plan* p, bool inverse, const void* src, void* dst
 
 int ndwt_dec_host(ndwt_plan* p, const void* x, void* y, int level) { return host_roundtrip(p, false, x, y, level); }
 int ndwt_rec_host(ndwt_plan* p, const void* y, void* x, int level) { return host_roundtrip(p, true, y, x, level); }
+
+// ---- consumers for iterative solvers (not in the reference: its users threshold in MATLAB) ----
+static int shrink_check(const ndwt_plan* p, int level, double thr, int mode) {
+    int rc = check_level(p, level);
+    if (rc) return rc;
+    if (!(thr >= 0.0)) return fail(NDWT_ERR_INVALID_ARG, "threshold must be >= 0");
+    if (mode != NDWT_SHRINK_SOFT && mode != NDWT_SHRINK_HARD) return fail(NDWT_ERR_INVALID_ARG, "mode must be NDWT_SHRINK_SOFT or NDWT_SHRINK_HARD");
+    return NDWT_OK;
+}
+
+int ndwt_shrink(ndwt_plan* p, void* y, int level, double threshold, int mode, void* stream) {
+    int rc = shrink_check(p, level, threshold, mode);
+    if (rc) return rc;
+    if (!y) return fail(NDWT_ERR_INVALID_ARG, "null data pointer");
+    HIP_TRY(hipSetDevice(p->device));
+    return p->dtype == NDWT_F32 ? shrink_impl<float>(p, (float*)y, level, threshold, mode, (hipStream_t)stream)
+                                : shrink_impl<double>(p, (double*)y, level, threshold, mode, (hipStream_t)stream);
+}
+
+int ndwt_denoise(ndwt_plan* p, const void* x, void* out, int level, double threshold, int mode, void* stream) {
+    int rc = shrink_check(p, level, threshold, mode);
+    if (rc) return rc;
+    if (!x || !out) return fail(NDWT_ERR_INVALID_ARG, "null data pointer");
+    HIP_TRY(hipSetDevice(p->device));
+    const size_t need = (size_t)p->vol * p->esize * (size_t)ndwt_num_bands(p->ndim, level);
+    if (need > p->coef_bytes) {
+        if (p->coef) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipFree(p->coef));
+            p->coef = nullptr;
+            p->coef_bytes = 0;
+        }
+        hipError_t e = hipMalloc(&p->coef, need);
+        if (e != hipSuccess) return fail(NDWT_ERR_ALLOC, "hipMalloc(%zu bytes) for the coefficient scratch failed: %s", need, hipGetErrorString(e));
+        p->coef_bytes = need;
+    }
+    rc = ndwt_dec(p, x, p->coef, level, stream);
+    if (rc == NDWT_OK) rc = ndwt_shrink(p, p->coef, level, threshold, mode, stream);
+    if (rc == NDWT_OK) rc = ndwt_rec(p, p->coef, out, level, stream);
+    return rc;
+}
+
+int ndwt_denoise_host(ndwt_plan* p, const void* x, void* out, int level, double threshold, int mode) {
+    int rc = shrink_check(p, level, threshold, mode);
+    if (rc) return rc;
+    if (!x || !out) return fail(NDWT_ERR_INVALID_ARG, "null data pointer");
+    HIP_TRY(hipSetDevice(p->device));
+    const size_t bx = (size_t)p->vol * p->esize;
+    void* dx = nullptr;
+    if (hipMalloc(&dx, bx) != hipSuccess) return fail(NDWT_ERR_ALLOC, "hipMalloc of the staging buffer (%zu bytes) failed", bx);
+    hipError_t e = hipMemcpy(dx, x, bx, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = ndwt_denoise(p, dx, dx, level, threshold, mode, nullptr);     // in place on the staging buffer (dec reads x before rec writes it)
+        if (rc == NDWT_OK) e = hipMemcpy(out, dx, bx, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(dx);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(NDWT_ERR_HIP, "staging copy failed: %s", hipGetErrorString(e));
+    return NDWT_OK;
+}
 
 // Split complex (separate real / imaginary arrays: mxGetPr / mxGetPi of nd_dwt_mex.c:55-58).  The filters are
 // real, so the complex transform is the real transform of each part: a REAL plan is run once per part.

@@ -216,6 +216,46 @@ def test_split_complex_entry_points_match_the_interleaved_transform():
         pc.dec_split(tx.data_ptr(), None, ty.data_ptr(), None, lev)
 
 
+def _np_shrink(c, t, hard):
+    m = np.abs(c)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        g = np.where(m > t, 1.0 if hard else (m - t) / np.where(m > 0, m, 1.0), 0.0)
+    out = c * g
+    out[..., 0] = c[..., 0]                                   # the coarsest approximation band is kept
+    return out
+
+
+@pytest.mark.parametrize("d,sizes,wn,cplx,precision", [
+    (3, [24, 18, 12], ["db2", "db4", "db1"], False, "double"),
+    (3, [20, 16, 9], ["db3", "db2", "db2"], True, "single"),
+    (2, [37, 21], ["db4", "db1"], True, "double"),           # odd sizes: scalar path of the shrink kernel
+    (1, [130], "db3", False, "single"),
+])
+def test_shrink_and_denoise_against_numpy(d, sizes, wn, cplx, precision):
+    """soft / hard thresholding of the detail bands and the one-call dec -> shrink -> rec (C-ABI extension for solvers)"""
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal(sizes) + (1j * rng.standard_normal(sizes) if cplx else 0)
+    w = _cls(d)(wn, sizes, "pres_l2_norm", 1, "precision", precision)
+    tol = TOL[precision]
+    wl = [wn] * d if isinstance(wn, str) else wn
+    y_ref = orc.spatial_dec(x, wl, 2, 1)
+    xg = _colmajor_gpu(x, precision)
+    y = w.dec(xg, 2)
+    for mode in ("soft", "hard"):
+        want = _np_shrink(y_ref, 0.4, mode == "hard")
+        got = w.shrink(y, 0.4, mode).cpu().numpy()
+        # elements within rounding of the threshold may fall on either side in single precision
+        near = np.abs(np.abs(y_ref) - 0.4) < 1e-4
+        assert np.abs(np.where(near, 0, got - want)).max() <= 10 * tol * np.abs(y_ref).max()
+        den = w.denoise(xg, 2, 0.4, mode).cpu().numpy()
+        want_x = orc.spatial_rec(np.where(near, got, want), wl, 1)
+        assert np.abs(den - want_x).max() <= 20 * tol * max(np.abs(want_x).max(), 1.0)
+    assert torch.equal(y, w.dec(xg, 2))                       # shrink() returned a copy
+    assert _relerr(w.denoise(xg, 2, 0.0).cpu().numpy(), x) < 20 * tol      # threshold 0 = identity
+    with pytest.raises(ndwt.NdwtError, match="threshold"):
+        w.denoise(xg, 2, -1.0)
+
+
 def test_properties_linearity_shift_adjoint():
     torch.manual_seed(0)
     sizes = [48, 36, 40]
