@@ -82,6 +82,8 @@ struct ndwt_plan {
     int num_cus;
     int fp64_fused;                    // fp64: fused 3-D kernels (1) or the per-axis march kernels (0)
     void* taps_dev[2];                 // device tap tables of the fused kernels: [0] analysis, [1] synthesis (Taps3<T, Lp>)
+    int shrink_mode;                   // ndwt_denoise, during its rec: 0 none, 1 soft, 2 hard -- fused into the synthesis kernels' loads
+    double shrink_thr;
     void* coef;                        // coefficient scratch of ndwt_denoise (all bands of the last level used), lazily allocated
     size_t coef_bytes;
     // optional per-kernel timing with HIP events on the launch stream (bench.py's roofline figures)
@@ -322,12 +324,17 @@ void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int
 // one fused 3-D launch over `nbatch` volumes. n3 = output planes; z_wrap=false: inputs carry the z halo
 template <typename T>
 static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* in, T* const* out, long long n3, long long nbatch,
-                      long long in_bstride, long long out_bstride, int z_mode, hipStream_t s, long long zlo = 0, long long zhi = LLONG_MIN, long long zbs = 0) {
+                      long long in_bstride, long long out_bstride, int z_mode, hipStream_t s, long long zlo = 0, long long zhi = LLONG_MIN, long long zbs = 0, int shrink_mask = 0) {
     Fused3Args<T> a;
     memset(&a, 0, sizeof a);
     a.zlo = (int)zlo;                                     // mode 3: input planes outside [zlo, zhi) read as zero
     a.zhi = (int)(zhi != LLONG_MIN ? zhi : n3 - (Lp - 1));
     a.zbs = (int)zbs;
+    if (inverse && p->shrink_mode && shrink_mask) {        // only reached with a lane-shift synthesis kernel (fused_shrink_capable)
+        a.shrink_thr = (T)p->shrink_thr;
+        a.shrink_mask = shrink_mask;
+        a.shrink_hard = p->shrink_mode == 2;
+    }
     a.n1 = (int)(p->dims[0] * p->comp);                   // scalars along x (interleaved complex: 2 per element)
     a.n2 = (int)p->dims[1];
     a.n3 = (int)n3;
@@ -389,6 +396,11 @@ static int fused2_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     a.in_bstride = in_bstride;
     a.out_bstride = out_bstride;
     a.y_wrap = y_wrap ? 1 : 0;
+    if (inverse && p->shrink_mode) {                     // ndwt_denoise: threshold the 3 detail bands as they are loaded
+        a.shrink_thr = (T)p->shrink_thr;
+        a.shrink_mask = 0xE;
+        a.shrink_hard = p->shrink_mode == 2;
+    }
     bool vec4 = (a.n1 % 4 == 0);
     const int nin = inverse ? 4 : 1, nout = inverse ? 1 : 4;
     for (int b = 0; b < nin; ++b) { a.in[b] = in[b]; vec4 = vec4 && aligned_vec4<T>(in[b]); }
@@ -463,7 +475,7 @@ static int synthesis_level(ndwt_plan* p, const T* const* in, T* out, long long s
         const long long vol3 = p->comp * p->dims[0] * p->dims[1] * p->dims[2];
         if (d == 3) {
             T* outs[8] = {out};
-            return fused3_run<T>(p, true, Lp, in, outs, p->dims[2], 1, vol_in, p->vol, slab ? 0 : 1, s);
+            return fused3_run<T>(p, true, Lp, in, outs, p->dims[2], 1, vol_in, p->vol, slab ? 0 : 1, s, 0, LLONG_MIN, 0, 0xFE);
         }
         int rc = ensure_tmp(p, (size_t)(2 * vol_in) * sizeof(T));
         if (rc) return rc;
@@ -471,9 +483,9 @@ static int synthesis_level(ndwt_plan* p, const T* const* in, T* out, long long s
         T* dd = a + vol_in;
         T* outs_a[8] = {a};
         T* outs_d[8] = {dd};
-        rc = fused3_run<T>(p, true, Lp, in, outs_a, p->dims[2], n_top_in, vol3, vol3, 1, s);
+        rc = fused3_run<T>(p, true, Lp, in, outs_a, p->dims[2], n_top_in, vol3, vol3, 1, s, 0, LLONG_MIN, 0, 0xFE);   // in[0] = approximation
         if (rc) return rc;
-        rc = fused3_run<T>(p, true, Lp, in + 8, outs_d, p->dims[2], n_top_in, vol3, vol3, 1, s);
+        rc = fused3_run<T>(p, true, Lp, in + 8, outs_d, p->dims[2], n_top_in, vol3, vol3, 1, s, 0, LLONG_MIN, 0, 0xFF);   // t-high half: all details
         if (rc) return rc;
         return axis_pass<T>(p, true, 3, p->dims, stride, !slab, a, dd, out, nullptr, s);
     }
@@ -892,6 +904,15 @@ static int host_roundtrip(ndwt_plan* p, bool inverse, const void* src, void* dst
 int ndwt_dec_host(ndwt_plan* p, const void* x, void* y, int level) { return host_roundtrip(p, false, x, y, level); }
 int ndwt_rec_host(ndwt_plan* p, const void* y, void* x, int level) { return host_roundtrip(p, true, y, x, level); }
 
+// true when every synthesis level of this plan runs a kernel that can shrink its inputs on load (Inv3S / Inv2S)
+static bool fused_shrink_capable(const ndwt_plan* p) {
+    if (p->dilation != NDWT_DILATION_REFERENCE) return false;         // dilated levels take the per-axis kernels
+    int Lp = 0;
+    if (fused2_eligible(p, 1, &Lp)) return true;
+    if (!fused3_eligible(p, 1, &Lp)) return false;
+    return !(p->variant_inv == 3 && Lp == 8);                        // A/B variant 3 = the LDS synthesis kernel
+}
+
 // ---- consumers for iterative solvers (not in the reference: its users threshold in MATLAB) ----
 static int shrink_check(const ndwt_plan* p, int level, double thr, int mode) {
     int rc = check_level(p, level);
@@ -928,7 +949,17 @@ int ndwt_denoise(ndwt_plan* p, const void* x, void* out, int level, double thres
         p->coef_bytes = need;
     }
     rc = ndwt_dec(p, x, p->coef, level, stream);
-    if (rc == NDWT_OK) rc = ndwt_shrink(p, p->coef, level, threshold, mode, stream);
+    if (rc) return rc;
+    if (fused_shrink_capable(p)) {
+        // every level is reconstructed by a lane-shift kernel: the detail bands are thresholded in registers as that
+        // kernel loads them, and the separate pass (a read and a write of every detail band) disappears
+        p->shrink_mode = mode == NDWT_SHRINK_HARD ? 2 : 1;
+        p->shrink_thr = threshold;
+        rc = ndwt_rec(p, p->coef, out, level, stream);
+        p->shrink_mode = 0;
+        return rc;
+    }
+    rc = ndwt_shrink(p, p->coef, level, threshold, mode, stream);
     if (rc == NDWT_OK) rc = ndwt_rec(p, p->coef, out, level, stream);
     return rc;
 }

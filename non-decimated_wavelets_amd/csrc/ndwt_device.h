@@ -48,6 +48,7 @@ NDWT_DEV long long modn64(long long v, long long n) {
     return m < 0 ? m + n : m;
 }
 
+
 // Compile-time loop: the per-thread register arrays (filter windows, prefetch buffers) must only ever be
 // indexed by constants that are visible BEFORE loop unrolling, otherwise hipcc merges the rotated
 // switch cases and the arrays fall into scratch memory.
@@ -59,6 +60,28 @@ template <int I, int N, class F> NDWT_DEV void static_for(F&& f) {
 }
 #define NDWT_SFOR(var, N) static_for<0, N>([&](auto var##_c) __attribute__((always_inline)) { constexpr int var = decltype(var##_c)::value;
 #define NDWT_SEND });
+
+NDWT_DEV float ndwt_sqrt(float v) { return __builtin_sqrtf(v); }
+NDWT_DEV double ndwt_sqrt(double v) { return __builtin_sqrt(v); }
+
+// soft / hard shrinkage of the 4 scalars one lane holds; EW = 2: two interleaved complex values, the magnitude shrinks
+template <typename T, int EW, class V4> NDWT_DEV void shrink4(V4& c, T thr, int hard) {
+    if constexpr (EW == 1) {
+        NDWT_SFOR(e, 4)
+            const T v = c[e];
+            const T m = v < T(0) ? -v : v;
+            c[e] = m > thr ? (hard ? v : (v < T(0) ? v + thr : v - thr)) : T(0);
+        NDWT_SEND
+    } else {
+        NDWT_SFOR(h, 2)
+            const T re = c[2 * h], im = c[2 * h + 1];
+            const T m = ndwt_sqrt(re * re + im * im);
+            const T g = m > thr ? (hard ? T(1) : (m - thr) / m) : T(0);
+            c[2 * h] = re * g;
+            c[2 * h + 1] = im * g;
+        NDWT_SEND
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Axis kernels (general path).  Array viewed as [outer][N][inner], inner contiguous.
@@ -147,6 +170,10 @@ template <typename T> struct Fused3Args {
                            // [zlo, zhi) read as 0 (whole slab: zlo = 0, zhi = n_in, n3 = n_in + L-1)
     int zlo, zhi;          // z_wrap == 3 only
     int zbs;               // z_wrap == 3: batch item i tests plane + i*zbs against [zlo, zhi) (runs of one slab)
+    // lane-shift synthesis only: shrink the input bands whose bit is set in shrink_mask as they are loaded (soft, or
+    // hard with shrink_hard) -- the thresholding of the detail bands fused into the reconstruction
+    T shrink_thr;
+    int shrink_mask, shrink_hard;
     int dbg;               // timing experiments only (wrong results): bit0 = fold halo reads back into the tile
 };
 
@@ -803,6 +830,17 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
         NDWT_SEND
     }
 
+    // thresholding fused into the reconstruction: every lane shrinks the band values it holds before the x-stage reads
+    // them (its own and, through the lane shifts, its neighbours')
+    static NDWT_DEV void shrink_raw(State& st, const Args& a) {
+        if (a.shrink_mask == 0) return;
+        NDWT_SFOR(k, NRND)
+            NDWT_SFOR(b, 8)
+                if ((a.shrink_mask >> b) & 1) shrink4<T, EW>(st.raw[k][b], a.shrink_thr, a.shrink_hard);
+            NDWT_SEND
+        NDWT_SEND
+    }
+
     // all 64 lanes of every wave execute the shifts (no divergence before them); only the LDS store is predicated
     template <class Exec> static NDWT_DEV void xsyn(Exec& ex, State& st, Shared& sh, const Taps& tp, int buf, int tid) {
         NDWT_SFOR(k, NRND)
@@ -930,6 +968,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
         });
         for (int p = 0; p < nplanes; ++p) {
             const int s = p - (L - 1);
+            ex.each([&](int, State& st) __attribute__((always_inline)) { shrink_raw(st, a); });
             ex.each([&](int tid, State& st) __attribute__((always_inline)) { xsyn(ex, st, sh, tp, p & 1, tid); });
             ex.each([&](int, State& st) __attribute__((always_inline)) {                 // (separate pass only matters to the host emulator)
                 if (p + 1 < nplanes) load_raw(st, a, ibase, tc.zbeg - LH + p + 1, zsh);
@@ -958,6 +997,8 @@ template <typename T> struct Fused2Args {
     int ntx, nyc;          // wave tiles along x, chunks along y
     int y_wrap;            // 1: periodic in y; 0: inputs start `left` rows before local row 0 (slab mode)
     int dbg;
+    T shrink_thr;          // synthesis: shrink input band b on load when bit b of shrink_mask is set
+    int shrink_mask, shrink_hard;
 };
 
 struct Tile2Coord {
@@ -1207,6 +1248,13 @@ template <typename T, int L_, bool VEC4_, int WPE_ = 4, int EW_ = 1> struct Inv2
         });
         for (int p = 0; p < nrows; ++p) {
             const int s = p - (L - 1);
+            ex.each([&](int, State& st) __attribute__((always_inline)) {               // fused thresholding of the detail bands
+                if (a.shrink_mask) {
+                    NDWT_SFOR(b, 4)
+                        if ((a.shrink_mask >> b) & 1) shrink4<T, EW>(st.raw[b], a.shrink_thr, a.shrink_hard);
+                    NDWT_SEND
+                }
+            });
             ex.each([&](int tid, State& st) __attribute__((always_inline)) {
                 dispatch<0>((p + 1) % L, ex, st, tp, a, tc, obase, tc.ybeg + s, s >= 0, tid);
             });

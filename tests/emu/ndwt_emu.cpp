@@ -73,7 +73,8 @@ int dispatch(int Lp, int vec4, ndwt::Fused3Args<T>& a, const double* lo, const d
 // (tests/emu/Makefile compiles this file once per EMU_PART, in parallel)
 template <typename T, bool INV>
 int emu3(int Lp, int vec4, const T* in, T* out, int n1, int n2, int n3, int nbatch, int zchunk,
-         const double* lo, const double* hi, int z_wrap, int small_tile, int variant, int ew) {
+         const double* lo, const double* hi, int z_wrap, int small_tile, int variant, int ew, double shrink_thr, int shrink_mask,
+         int shrink_hard) {
     ndwt::Fused3Args<T> a;
     std::memset(&a, 0, sizeof(a));
     a.n1 = n1; a.n2 = n2; a.n3 = n3; a.nbatch = nbatch;
@@ -83,6 +84,7 @@ int emu3(int Lp, int vec4, const T* in, T* out, int n1, int n2, int n3, int nbat
     a.z_wrap = z_wrap;
     a.zlo = 0;
     a.zhi = n3 - (Lp - 1);
+    if (INV) { a.shrink_thr = (T)shrink_thr; a.shrink_mask = shrink_mask; a.shrink_hard = shrink_hard; }
     a.in_bstride = vol_in; a.out_bstride = vol;
     if constexpr (!INV) {
         a.in[0] = in;
@@ -160,13 +162,14 @@ template <class K, typename T> int run2(ndwt::Fused2Args<T>& a, const double* lo
 
 template <typename T>
 int emu2(int inverse, int Lp, int vec4, const T* in, T* out, int n1, int n2, int ychunk, const double* lo, const double* hi,
-         int y_wrap, int ew) {
+         int y_wrap, int ew, double shrink_thr, int shrink_mask, int shrink_hard) {
     ndwt::Fused2Args<T> a;
     std::memset(&a, 0, sizeof(a));
     a.n1 = n1; a.n2 = n2; a.nbatch = 1;
     const long long vol = (long long)n1 * n2;
     const long long vol_in = y_wrap ? vol : (long long)n1 * (n2 + Lp - 1);
     a.y_wrap = y_wrap;
+    if (inverse) { a.shrink_thr = (T)shrink_thr; a.shrink_mask = shrink_mask; a.shrink_hard = shrink_hard; }
     a.in_bstride = vol_in; a.out_bstride = vol;
     if (!inverse) {
         a.in[0] = in;
@@ -312,20 +315,21 @@ int ndwt_emu_march_f64(int syn, int L, const double* in0, const double* in1, dou
 #endif
 #if EMU_IN(3)
 int ndwt_emu2_f32(int inverse, int Lp, int vec4, const float* in, float* out, int n1, int n2, int ychunk, const double* lo,
-                  const double* hi, int y_wrap, int ew) {
-    return emu2<float>(inverse, Lp, vec4, in, out, n1, n2, ychunk, lo, hi, y_wrap, ew);
+                  const double* hi, int y_wrap, int ew, double shrink_thr, int shrink_mask, int shrink_hard) {
+    return emu2<float>(inverse, Lp, vec4, in, out, n1, n2, ychunk, lo, hi, y_wrap, ew, shrink_thr, shrink_mask, shrink_hard);
 }
 #endif
 #if EMU_IN(4)
 int ndwt_emu2_f64(int inverse, int Lp, int vec4, const double* in, double* out, int n1, int n2, int ychunk, const double* lo,
-                  const double* hi, int y_wrap, int ew) {
-    return emu2<double>(inverse, Lp, vec4, in, out, n1, n2, ychunk, lo, hi, y_wrap, ew);
+                  const double* hi, int y_wrap, int ew, double shrink_thr, int shrink_mask, int shrink_hard) {
+    return emu2<double>(inverse, Lp, vec4, in, out, n1, n2, ychunk, lo, hi, y_wrap, ew, shrink_thr, shrink_mask, shrink_hard);
 }
 #endif
 // in/out: band-planar, batch inside band: [band][batch][n3(+halo)][n2][n1]; lo/hi: [3][20] padded kernel-form taps
 #define EMU3_ARGS(T) int Lp, int vec4, const T* in, T* out, int n1, int n2, int n3, int nbatch, int zchunk, const double* lo, \
-                     const double* hi, int z_wrap, int small_tile, int variant, int ew
-#define EMU3_PASS Lp, vec4, in, out, n1, n2, n3, nbatch, zchunk, lo, hi, z_wrap, small_tile, variant, ew
+                     const double* hi, int z_wrap, int small_tile, int variant, int ew, double shrink_thr, int shrink_mask, \
+                     int shrink_hard
+#define EMU3_PASS Lp, vec4, in, out, n1, n2, n3, nbatch, zchunk, lo, hi, z_wrap, small_tile, variant, ew, shrink_thr, shrink_mask, shrink_hard
 #if EMU_IN(5)
 int ndwt_emu3_f32_fwd(EMU3_ARGS(float)) { return emu3<float, false>(EMU3_PASS); }
 #endif

@@ -29,7 +29,7 @@ def emu():
     return ctypes.CDLL(os.path.join(ROOT, "tests", "emu", target))
 
 
-def _run(emu, x_mat_or_bands, wnames, l2, inverse, dtype, vec4, zchunk, small, z_wrap=1, variant=0, cplx=False):
+def _run(emu, x_mat_or_bands, wnames, l2, inverse, dtype, vec4, zchunk, small, z_wrap=1, variant=0, cplx=False, shrink=(0.0, 0, 0)):
     Ls = [len(orc.wave_filters(w)[0]) for w in wnames]
     Lp = max(Ls)
     lo = np.zeros((3, 20))
@@ -52,7 +52,7 @@ def _run(emu, x_mat_or_bands, wnames, l2, inverse, dtype, vec4, zchunk, small, z
     fn.restype = ctypes.c_int
     rc = fn(int(inverse), Lp, int(vec4), src.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p),
             n1, n2, n3, 1, zchunk, lo.ctypes.data_as(ctypes.c_void_p), hi.ctypes.data_as(ctypes.c_void_p), z_wrap,
-            int(small), int(variant), 2 if cplx else 1)
+            int(small), int(variant), 2 if cplx else 1, ctypes.c_double(shrink[0]), int(shrink[1]), int(shrink[2]))
     assert rc == 0
     return np.transpose(out)
 
@@ -100,7 +100,7 @@ def test_emulated_fused3_synthesis(emu, sizes, wn, vec4, zchunk, small, l2):
             assert np.abs(got - want).max() <= tol * max(np.abs(want).max(), 1.0)
 
 
-def _run2(emu, arr, wnames, l2, inverse, dtype, vec4, ychunk, cplx=False):
+def _run2(emu, arr, wnames, l2, inverse, dtype, vec4, ychunk, cplx=False, shrink=(0.0, 0, 0)):
     Ls = [len(orc.wave_filters(w)[0]) for w in wnames]
     Lp = max(Ls)
     lo = np.zeros((3, 20))
@@ -122,7 +122,8 @@ def _run2(emu, arr, wnames, l2, inverse, dtype, vec4, ychunk, cplx=False):
     fn = emu.ndwt_emu2_f32 if dtype == np.float32 else emu.ndwt_emu2_f64
     fn.restype = ctypes.c_int
     rc = fn(int(inverse), Lp, int(vec4), src.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), n1, n2, ychunk,
-            lo.ctypes.data_as(ctypes.c_void_p), hi.ctypes.data_as(ctypes.c_void_p), 1, 2 if cplx else 1)
+            lo.ctypes.data_as(ctypes.c_void_p), hi.ctypes.data_as(ctypes.c_void_p), 1, 2 if cplx else 1, ctypes.c_double(shrink[0]),
+            int(shrink[1]), int(shrink[2]))
     assert rc == 0
     return np.transpose(out)
 
@@ -278,3 +279,37 @@ def test_emulated_fused2_interleaved_complex(emu, sizes, wn, vec4, ychunk):
         assert np.isfinite(got).all() and np.abs(got - want_y).max() <= tol * np.abs(want_y).max()
         got = _run2(emu, c, wn, 0, True, dtype, vec4, ychunk, cplx=True)
         assert np.isfinite(got).all() and np.abs(got - want_r).max() <= tol * max(np.abs(want_r).max(), 1.0)
+
+
+def _np_shrink_bands(c, t, hard, mask):
+    m = np.abs(c)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        g = np.where(m > t, 1.0 if hard else (m - t) / np.where(m > 0, m, 1.0), 0.0)
+    out = c * g
+    for b in range(c.shape[-1]):
+        if not (mask >> b) & 1:
+            out[..., b] = c[..., b]
+    return out
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("hard", [0, 1])
+def test_emulated_synthesis_with_fused_shrinkage(emu, cplx, hard):
+    """the lane-shift synthesis kernels threshold the bands selected by shrink_mask as they load them (ndwt_denoise)"""
+    rng = np.random.default_rng(12)
+    # 3-D: production tile (variant 1) and small tile (variant 2)
+    for sizes, wn, vec4, zchunk, small, variant in (((68, 18, 9), ("db4", "db2", "db4"), True, 0, False, 1),
+                                                    ((20, 9, 7), ("db2", "db3", "db1"), True, 4, True, 2)):
+        c = rng.standard_normal(tuple(sizes) + (8,)) + (1j * rng.standard_normal(tuple(sizes) + (8,)) if cplx else 0)
+        filt = [orc.wave_filters(w) for w in wn]
+        want = orc.spatial_level_rec(_np_shrink_bands(c, 0.5, hard, 0xFE), filt, 1)
+        got = _run(emu, c, wn, 1, True, np.float64, vec4, zchunk, small, variant=variant, cplx=cplx, shrink=(0.5, 0xFE, hard))
+        assert np.abs(got - want).max() <= 1e-12 * max(np.abs(want).max(), 1.0)
+    # 2-D
+    sizes, wn = (150, 20), ("db4", "db2")
+    c = rng.standard_normal(tuple(sizes) + (4,)) + (1j * rng.standard_normal(tuple(sizes) + (4,)) if cplx else 0)
+    filt = [orc.wave_filters(w) for w in wn]
+    want = orc.spatial_level_rec(_np_shrink_bands(c, 0.5, hard, 0xE), filt, 1)
+    got = _run2(emu, c, wn, 1, True, np.float64, True, 7, cplx=cplx, shrink=(0.5, 0xE, hard))
+    assert np.abs(got - want).max() <= 1e-12 * max(np.abs(want).max(), 1.0)
