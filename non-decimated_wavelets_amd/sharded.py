@@ -132,6 +132,9 @@ class ShardedNdDwt:
         self.scheme = synthesis_scheme
         self.nb = 1 << self.d
         self._exchange_cache = {}
+        # gloo moves host memory only: GPU slabs exchanged over gloo (debugging / rehearsing ranks that share one GPU) are
+        # staged through host copies.  RCCL ("nccl") sends the device buffers as they are.
+        self._host_stage = bool(self.device.type == "cuda" and dist.is_initialized() and dist.get_backend(group) == "gloo")
         # overlap of the exchange with the planes that do not depend on it needs the run-of-planes entry points
         self.overlap = bool(overlap and self.scheme == "scatter" and hasattr(self.engine, "analysis_run")
                             and hasattr(self.engine, "synthesis_part"))
@@ -197,13 +200,15 @@ class ShardedNdDwt:
                 dst.copy_(src)
             elif p == self.rank:
                 buf = src if src.is_contiguous() else src.contiguous()
+                if self._host_stage:
+                    buf = buf.cpu()
                 keep.append(buf)
                 ops.append(dist.P2POp(dist.isend, buf, self._global_rank(q), self.group))
             else:
-                if dst.is_contiguous():
+                if dst.is_contiguous() and not self._host_stage:
                     ops.append(dist.P2POp(dist.irecv, dst, self._global_rank(p), self.group))
                 else:
-                    buf = torch.empty(dst.shape, dtype=dst.dtype, device=dst.device)
+                    buf = torch.empty(dst.shape, dtype=dst.dtype, device="cpu" if self._host_stage else dst.device)
                     ops.append(dist.P2POp(dist.irecv, buf, self._global_rank(p), self.group))
                     post.append(lambda dst=dst, buf=buf: dst.copy_(buf))
         works = dist.batch_isend_irecv(ops) if ops else []
@@ -220,7 +225,7 @@ class ShardedNdDwt:
     def _start_scatter(self, part_before, part_after, before, after):
         """Posts the sends of the partial planes this rank owes (part_before: for the `before` planes ahead of its
         slab, part_after: for the `after` planes behind it) and the receives of what it is owed."""
-        ops, adds_local, adds_recv = [], [], []
+        ops, adds_local, adds_recv, keep = [], [], [], []
         parts = (part_before, part_after)
         # rank q PRODUCES partial planes for the global planes around its slab; the owner p ADDS them
         for q, side, p, k0, l0, n in self._plan_exchange(before, after):
@@ -229,21 +234,24 @@ class ShardedNdDwt:
                 if p == self.rank:
                     adds_local.append((l0, n, part))
                 else:
+                    if self._host_stage:
+                        part = part.cpu()
+                        keep.append(part)
                     ops.append(dist.P2POp(dist.isend, part, self._global_rank(p), self.group))
             elif p == self.rank:
                 ref = parts[side]
-                buf = torch.empty([n] + list(ref.shape[1:]), dtype=ref.dtype, device=ref.device)
+                buf = torch.empty([n] + list(ref.shape[1:]), dtype=ref.dtype, device="cpu" if self._host_stage else ref.device)
                 ops.append(dist.P2POp(dist.irecv, buf, self._global_rank(q), self.group))
                 adds_recv.append((l0, n, buf))
         works = dist.batch_isend_irecv(ops) if ops else []
-        return works, adds_local + adds_recv, parts
+        return works, adds_local + adds_recv, (parts, keep)
 
     def _finish_scatter(self, pending, own):
         works, adds, _keep = pending
         for w in works:
             w.wait()
         for l0, n, buf in adds:
-            own.narrow(0, l0, n).add_(buf)
+            own.narrow(0, l0, n).add_(buf if buf.device == own.device else buf.to(own.device))
 
     def _global_rank(self, r):
         return r if self.group is None or self.group is dist.group.WORLD else dist.get_global_rank(self.group, r)

@@ -423,3 +423,56 @@ def test_fused2d_kernels_at_baseline_config2_shape():
     p.set_path(True)
     yg = w.dec(x, 3)
     assert float((y - yg).abs().max()) <= 2e-6 * float(yg.abs().max())
+
+
+def _two_rank_worker(rank, world, port, q):
+    """one of `world` processes that share cuda:0; slabs are exchanged over gloo (host staged)"""
+    import importlib
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sh = importlib.import_module("non-decimated_wavelets_amd.sharded")
+        n1, n2, n3, level = 72, 40, 50, 3                    # 50 planes over 3 ranks: uneven slabs
+        dev = torch.device("cuda", 0)
+        torch.manual_seed(5)
+        xs = torch.randn(n3, n2, n1, device=dev)               # same volume on every rank
+        w = ndwt.nd_dwt_3D("db4", [n1, n2, n3], "pres_l2_norm", 1, "precision", "single")
+        yref = w.dec(xs.permute(2, 1, 0), level).permute(3, 2, 1, 0)
+        errs = []
+        for overlap in (True, False):
+            eng = sh.ShardedNdDwt(["db4"] * 3, [n1, n2, n3], pres_l2_norm=True, precision="single", device=dev, overlap=overlap)
+            assert eng.scheme == "scatter" and eng.overlap == overlap and eng._host_stage
+            yl = eng.dec(xs[eng.z0:eng.z1].contiguous(), level)
+            e_dec = float((yl - yref[:, eng.z0:eng.z1]).abs().max() / yref.abs().max())
+            xl = eng.rec(yl)
+            e_rec = float((xl - xs[eng.z0:eng.z1]).abs().max())
+            errs.append((e_dec, e_rec))
+        q.put((rank, errs))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_three_ranks_share_one_gpu_over_gloo():
+    """the product slab engine (HIP kernels, run-of-planes entry points, in-place halo margins) under a real
+    multi-process exchange: 3 processes on cuda:0, gloo with host staging standing in for RCCL"""
+    import socket
+    import torch.multiprocessing as mp
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 3
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, errs in res:
+        for e_dec, e_rec in errs:
+            assert e_dec <= 2e-6 and e_rec <= 1e-5, (rank, errs)
