@@ -87,13 +87,22 @@ def main():
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    # rehearsal of the N > 1 path on a one-GPU box: NDWT_BENCH_BACKEND=gloo (slabs staged through the host) with
+    # NDWT_BENCH_ONE_GPU=1 (every rank on device 0).  The driver's runs use neither: one rank per GPU over RCCL.
+    backend = os.environ.get("NDWT_BENCH_BACKEND", "nccl")
+    if os.environ.get("NDWT_BENCH_ONE_GPU", "0") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")     # where the scalar reductions of the report live
 
     n1, n2, n3 = a.size
     V = n1 * n2 * n3
@@ -144,7 +153,7 @@ def main():
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     if dist:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=red_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     prof = {k: plan.get_profile(k) for k in kinds}
@@ -156,6 +165,7 @@ def main():
         num = torch.linalg.vector_norm((r_holder["r"] - x).double()) ** 2
         den = torch.linalg.vector_norm(x.double()) ** 2
         if dist:
+            num, den = num.to(red_dev), den.to(red_dev)
             dist.all_reduce(num)
             dist.all_reduce(den)
         rt_err = float(torch.sqrt(num / den))
