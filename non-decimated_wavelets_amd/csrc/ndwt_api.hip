@@ -357,7 +357,9 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     const bool small_inv = inverse && sizeof(T) == 4 && (variant == 2 || variant == 3) && Lp == 8;   // 256-thread A/B variants
     const int per_cu = inverse ? (small_inv ? 3 : 1) : 2;
     const int target = p->target_blocks > 0 ? p->target_blocks : p->num_cus * per_cu;
-    fused3_geometry(a, TX, TY, Lp, target, zc_force);
+    // analysis (2-3 workgroups per CU): more tiles than resident slots -> about 8 workgroups per CU; synthesis (1 per CU,
+    // rounds are exact multiples of the CU count more often): one chunk per tile
+    fused3_geometry(a, TX, TY, Lp, target, zc_force, inverse || p->target_blocks > 0 ? 0 : p->num_cus * 8);
     FusedTapsD t = fused_taps(p, Lp, inverse);
     const void* td = p->taps_dev[inverse ? 1 : 0];
     if (!td) return fail(NDWT_ERR_UNSUPPORTED, "plan has no device tap table");
