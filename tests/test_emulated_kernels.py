@@ -307,7 +307,7 @@ def test_emulated_synthesis_with_fused_shrinkage(emu, cplx, hard):
         got = _run(emu, c, wn, 1, True, np.float64, vec4, zchunk, small, variant=variant, cplx=cplx, shrink=(0.5, 0xFE, hard))
         assert np.abs(got - want).max() <= 1e-12 * max(np.abs(want).max(), 1.0)
     # 2-D
-    sizes, wn = (150, 20), ("db4", "db2")
+    sizes, wn = (152, 20), ("db4", "db2")             # vec4 path: rows are a multiple of 4 scalars
     c = rng.standard_normal(tuple(sizes) + (4,)) + (1j * rng.standard_normal(tuple(sizes) + (4,)) if cplx else 0)
     filt = [orc.wave_filters(w) for w in wn]
     want = orc.spatial_level_rec(_np_shrink_bands(c, 0.5, hard, 0xE), filt, 1)
