@@ -407,7 +407,7 @@ static int fused2_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     const int nin = inverse ? 4 : 1, nout = inverse ? 1 : 4;
     for (int b = 0; b < nin; ++b) { a.in[b] = in[b]; vec4 = vec4 && aligned_vec4<T>(in[b]); }
     for (int b = 0; b < nout; ++b) { a.out[b] = out[b]; vec4 = vec4 && aligned_vec4<T>(out[b]); }
-    fused2_geometry(a, fused2_tile_width(inverse, Lp, (int)p->comp), Lp, p->target_blocks > 0 ? p->target_blocks * 2 : 4096, p->force_zchunk);
+    fused2_geometry(a, fused2_tile_width(inverse, Lp, (int)p->comp), Lp, p->target_blocks > 0 ? p->target_blocks * 2 : 2048, p->force_zchunk);   // 8 waves per CU: one round (measured optimum 1024^2 .. 4096^2)
     const void* td = p->taps_dev[inverse ? 1 : 0];
     if (!td) return fail(NDWT_ERR_UNSUPPORTED, "plan has no device tap table");
     prof_begin(p, inverse ? NDWT_KERNEL_FUSED_SYNTHESIS : NDWT_KERNEL_FUSED_ANALYSIS, s);
