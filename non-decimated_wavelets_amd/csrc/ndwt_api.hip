@@ -276,6 +276,24 @@ static bool fused3_eligible(const ndwt_plan* p, long long stride, int* Lp_out) {
     return true;
 }
 
+// A dilated (a-trous) 3-D level whose axes all divide by the tap stride s is s^3 independent stride-1 problems on the
+// sub-lattices: the fused kernels take x with the taps stepping over s interleaved scalars (the EW parameter, as for
+// interleaved complex data) and the s^2 (y, z) sub-lattices as batch items with row / plane strides s*n1, s*n1*n2.
+static bool fused3_dilated_eligible(const ndwt_plan* p, long long stride, int* Lp_out) {
+    if (p->path != NDWT_PATH_AUTO || p->ndim != 3 || p->complexity != NDWT_REAL) return false;
+    if (stride != 2 && !(stride == 4 && p->dtype == NDWT_F32)) return false;   // instantiated: EW = 2 (float, double), EW = 4 (float)
+    if (p->dtype == NDWT_F64 && !p->fp64_fused) return false;
+    int Lp = 2;
+    for (int a = 0; a < 3; ++a) Lp = p->filt[a].len > Lp ? p->filt[a].len : Lp;
+    if (Lp > 8) return false;
+    for (int a = 0; a < 3; ++a)
+        if (p->dims[a] % stride != 0) return false;
+    if (p->dims[0] % 4 != 0) return false;
+    if (!fused3_fits(p->dims[0], p->dims[1], p->dims[2] + 64, stride * stride)) return false;
+    *Lp_out = Lp;
+    return true;
+}
+
 static bool fused2_eligible(const ndwt_plan* p, long long stride, int* Lp_out) {
     if (p->path != NDWT_PATH_AUTO || stride != 1 || p->ndim != 2) return false;
     int Lp = p->filt[0].len > p->filt[1].len ? p->filt[0].len : p->filt[1].len;
@@ -310,12 +328,13 @@ template <> int launch3<double>(bool inverse, const Fused3Args<double>& a, const
 }
 
 namespace ndwt {
-void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int* TY) {
+void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int* TY, int dil) {
     (void)Lp;
     *TX = 64;
     *TY = f64 ? 8 : 16;
     if (!f64 && inverse && !((variant == 2 || variant == 3) && Lp == 8)) *TY = 32;   // float synthesis default: tall tile
     if (!f64 && !inverse && variant == 2 && (Lp == 8 || Lp == 12)) *TY = 32;
+    if (!f64 && inverse && dil == 4) *TY = 16;                                         // x taps over 4 scalars: 64x16 / 512 threads
     if (f64 && !inverse && Lp >= 10) *TY = 16;                                         // double analysis, db5/db6: 512 threads
     if (f64 && inverse && !(variant == 3 && Lp == 8)) *TY = 16;                        // double synthesis default: lane-shift kernel, 64x16
 }
@@ -324,7 +343,7 @@ void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int
 // one fused 3-D launch over `nbatch` volumes. n3 = output planes; z_wrap=false: inputs carry the z halo
 template <typename T>
 static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* in, T* const* out, long long n3, long long nbatch,
-                      long long in_bstride, long long out_bstride, int z_mode, hipStream_t s, long long zlo = 0, long long zhi = LLONG_MIN, long long zbs = 0, int shrink_mask = 0) {
+                      long long in_bstride, long long out_bstride, int z_mode, hipStream_t s, long long zlo = 0, long long zhi = LLONG_MIN, long long zbs = 0, int shrink_mask = 0, int dil = 1) {
     Fused3Args<T> a;
     memset(&a, 0, sizeof a);
     a.zlo = (int)zlo;                                     // mode 3: input planes outside [zlo, zhi) read as zero
@@ -336,9 +355,9 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
         a.shrink_hard = p->shrink_mode == 2;
     }
     a.n1 = (int)(p->dims[0] * p->comp);                   // scalars along x (interleaved complex: 2 per element)
-    a.n2 = (int)p->dims[1];
-    a.n3 = (int)n3;
-    a.nbatch = (int)nbatch;
+    a.n2 = (int)(p->dims[1] / dil);                       // dil > 1: one (y, z) sub-lattice per batch item
+    a.n3 = (int)(n3 / dil);
+    a.nbatch = (int)(dil > 1 ? dil * dil : nbatch);
     a.in_bstride = in_bstride;
     a.out_bstride = out_bstride;
     a.z_wrap = z_mode;
@@ -349,22 +368,29 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     for (int b = 0; b < nout; ++b) { a.out[b] = out[b]; vec4 = vec4 && aligned_vec4<T>(out[b]); }
     int TX = 0, TY = 0;
     const int variant = inverse ? p->variant_inv : p->variant_fwd;
-    fused3_tile_shape(sizeof(T) == 8, inverse, variant, Lp, &TX, &TY);
+    fused3_tile_shape(sizeof(T) == 8, inverse, variant, Lp, &TX, &TY, dil);
     const int zc_force = p->zchunk_dir[inverse ? 1 : 0] > 0 ? p->zchunk_dir[inverse ? 1 : 0] : p->force_zchunk;
     // One round of workgroups that all fit on the chip at once beats several partial rounds (measured, 512^3 float
     // analysis: 512 workgroups 0.88 ms, 1024: 1.09 ms, 2048: 0.99 ms; 256^3 double synthesis: 256 workgroups 0.36 ms,
     // 640: 0.48 ms).  Workgroups per CU: synthesis 1 (1024 threads / 94 KB of LDS), analysis 2 (3 fit, 2 run faster).
     const bool small_inv = inverse && sizeof(T) == 4 && (variant == 2 || variant == 3) && Lp == 8;   // 256-thread A/B variants
-    const int per_cu = inverse ? (small_inv ? 3 : 1) : 2;
+    const int per_cu = inverse ? (small_inv ? 3 : 1) : (dil == 4 ? 1 : 2);
     const int target = p->target_blocks > 0 ? p->target_blocks : p->num_cus * per_cu;
     // analysis (2-3 workgroups per CU): more tiles than resident slots -> about 8 workgroups per CU; synthesis (1 per CU,
     // rounds are exact multiples of the CU count more often): one chunk per tile
     fused3_geometry(a, TX, TY, Lp, target, zc_force, inverse || p->target_blocks > 0 ? 0 : p->num_cus * 8);
+    if (dil > 1) {
+        a.rs = (int)(dil * p->dims[0]);
+        a.plane = (long long)dil * p->dims[0] * p->dims[1];
+        a.bsplit = dil;
+        a.in_bstride = a.out_bstride = p->dims[0];                         // sub-lattice offset along y ...
+        a.in_bstride2 = a.out_bstride2 = p->dims[0] * p->dims[1];          // ... and along z
+    }
     FusedTapsD t = fused_taps(p, Lp, inverse);
     const void* td = p->taps_dev[inverse ? 1 : 0];
     if (!td) return fail(NDWT_ERR_UNSUPPORTED, "plan has no device tap table");
     prof_begin(p, inverse ? NDWT_KERNEL_FUSED_SYNTHESIS : NDWT_KERNEL_FUSED_ANALYSIS, s);
-    int rc = launch3<T>(inverse, a, t, vec4, variant, (int)p->comp, td, s);
+    int rc = launch3<T>(inverse, a, t, vec4, variant, dil > 1 ? dil : (int)p->comp, td, s);
     prof_end(p, s);
     if (rc == -1) return fail(NDWT_ERR_UNSUPPORTED, "no fused kernel instantiated for tap length %d", Lp);
     if (rc != 0) return fail(NDWT_ERR_HIP, "fused kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -428,6 +454,10 @@ static int analysis_level(ndwt_plan* p, const T* in, T* const* out, long long st
     const long long n_top_in = slab ? n_top + (long long)(ftop.len - 1) * stride : n_top;
     const long long vol_in = p->vol / n_top * n_top_in;
     int Lp = 0;
+    if (!slab && fused3_dilated_eligible(p, stride, &Lp)) {
+        const T* ins[8] = {in};
+        return fused3_run<T>(p, false, Lp, ins, out, p->dims[2], 1, 0, 0, 1, s, 0, LLONG_MIN, 0, 0, (int)stride);
+    }
     // slab mode hands over exactly (L_top-1) halo planes: the fused kernel marches with the padded length
     if (fused3_eligible(p, stride, &Lp) && !(slab && d == 3 && ftop.len != Lp)) {
         const long long vol3 = p->comp * p->dims[0] * p->dims[1] * p->dims[2];
@@ -473,6 +503,10 @@ static int synthesis_level(ndwt_plan* p, const T* const* in, T* out, long long s
     const long long n_top_in = slab ? n_top + (long long)(ftop.len - 1) * stride : n_top;
     const long long vol_in = p->vol / n_top * n_top_in;
     int Lp = 0;
+    if (!slab && fused3_dilated_eligible(p, stride, &Lp)) {
+        T* outs[8] = {out};
+        return fused3_run<T>(p, true, Lp, in, outs, p->dims[2], 1, 0, 0, 1, s, 0, LLONG_MIN, 0, 0, (int)stride);
+    }
     if (fused3_eligible(p, stride, &Lp) && !(slab && d == 3 && ftop.len != Lp)) {
         const long long vol3 = p->comp * p->dims[0] * p->dims[1] * p->dims[2];
         if (d == 3) {

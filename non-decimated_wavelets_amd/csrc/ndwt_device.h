@@ -161,7 +161,10 @@ template <typename T> struct Fused3Args {
     int nbatch;
     long long in_bstride;  // elements between batch items, inputs
     long long out_bstride; // elements between batch items, outputs
-    long long plane;       // n1*n2
+    long long plane;       // elements between planes (n1*n2; dilated levels: stride * n1 * n2)
+    int rs;                // elements between rows (n1; dilated levels: stride * n1)
+    int bsplit;            // > 0: batch item b starts at (b % bsplit) * bstride + (b / bsplit) * bstride2 (the stride^2 (y, z)
+    long long in_bstride2, out_bstride2;   // sub-lattices of a dilated level; x is handled by EW = stride)
     int zchunk;            // output planes per workgroup
     int ntx, nty, nzc;     // tiles per axis
     int z_wrap;            // outer axis: 1 periodic; 0 inputs start `left` planes before local plane 0 (haloed slab);
@@ -180,6 +183,10 @@ template <typename T> struct Fused3Args {
 // XCD-aware block order: hardware deals workgroups round-robin over the 8 XCDs (each with its own
 // L2), so give every XCD a contiguous run of logical tiles -- x/y neighbours then share halo rows
 // through one L2.  Speed only; any placement is correct.
+NDWT_DEV long long batch_base(int b, int bsplit, long long bs1, long long bs2) {
+    return bsplit > 0 ? (long long)(b % bsplit) * bs1 + (long long)(b / bsplit) * bs2 : (long long)b * bs1;
+}
+
 NDWT_DEV int xcd_remap(int bid, int nblocks) {
     const int nx = 8;
     int q = nblocks / nx, r = nblocks % nx;
@@ -321,7 +328,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
             int xb = tc.x0 - 4 * GL + 4 * ug;
             if (a.dbg & 1) { y = modn(tc.y0 + r % TY, a.n2); xb = tc.x0 + 4 * (ug % (TX / 4)); }
             NDWT_SFOR(e, NE)
-                st.off[k][e] = y * a.n1 + modn(xb + e, a.n1);
+                st.off[k][e] = y * a.rs + modn(xb + e, a.n1);
             NDWT_SEND
         NDWT_SEND
     }
@@ -438,7 +445,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
                 }
                 o00[e] = lo.x; o01[e] = lo.y; o10[e] = hi.x; o11[e] = hi.y;
             }
-            long long off = obase + (long long)z * a.plane + (long long)gy * a.n1 + gx;
+            long long off = obase + (long long)z * a.plane + (long long)gy * a.rs + gx;
             T* b00 = a.out[2 * q] + off;
             T* b10 = a.out[2 * q + 1] + off;
             T* b01 = a.out[2 * q + 4] + off;
@@ -459,8 +466,8 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
 
     template <class Exec> static NDWT_DEV void block(Exec& ex, Shared& sh, const Args& a, const Taps& tp, int bid) {
         const TileCoord tc = decode_tile(a, bid, TX, TY);
-        const T* inb = a.in[0] + (long long)tc.batch * a.in_bstride;
-        const long long obase = (long long)tc.batch * a.out_bstride;
+        const T* inb = a.in[0] + batch_base(tc.batch, a.bsplit, a.in_bstride, a.in_bstride2);
+        const long long obase = batch_base(tc.batch, a.bsplit, a.out_bstride, a.out_bstride2);
         // planes zbeg-LH .. zbeg-LH+L-2 into slots 0..L-2, then prefetch the plane of step 0
         ex.each([&](int tid, State& st) __attribute__((always_inline)) {
             setup(st, a, tc, tid);
@@ -536,7 +543,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
             int xb = tc.x0 - 4 * GL + 4 * ug;
             if (a.dbg & 1) { y = modn(tc.y0 + r % TY, a.n2); xb = tc.x0 + 4 * (ug % (TX / 4)); }
             NDWT_SFOR(e, NE)
-                st.off[k][e] = y * a.n1 + modn(xb + e, a.n1);
+                st.off[k][e] = y * a.rs + modn(xb + e, a.n1);
             NDWT_SEND
         NDWT_SEND
     }
@@ -649,7 +656,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
                         NDWT_SEND
                         int gy = tc.y0 + yg * RY + i;
                         if (gy < a.n2) {
-                            T* dst = a.out[0] + obase + (long long)z * a.plane + (long long)gy * a.n1 + gx;
+                            T* dst = a.out[0] + obase + (long long)z * a.plane + (long long)gy * a.rs + gx;
                             if constexpr (VEC4 && CH == 2) {
                                 if (gx < a.n1) *reinterpret_cast<v2*>(dst) = v2{o[0], o[CH - 1]};
                             } else {
@@ -674,8 +681,8 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
 
     template <class Exec> static NDWT_DEV void block(Exec& ex, Shared& sh, const Args& a, const Taps& tp, int bid) {
         const TileCoord tc = decode_tile(a, bid, TX, TY);
-        const long long ibase = (long long)tc.batch * a.in_bstride;
-        const long long obase = (long long)tc.batch * a.out_bstride;
+        const long long ibase = batch_base(tc.batch, a.bsplit, a.in_bstride, a.in_bstride2);
+        const long long obase = batch_base(tc.batch, a.bsplit, a.out_bstride, a.out_bstride2);
         const int zsh = tc.batch * a.zbs;
         const int nsteps = tc.zend - tc.zbeg;
         const int nplanes = nsteps + L - 1;              // planes zbeg-LH .. zend-1+RH
@@ -797,7 +804,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
             int xb = tc.x0 - 4 * GL + 4 * ug;
             if (a.dbg & 1) { y = modn(tc.y0 + r % TY, a.n2); xb = tc.x0 + 4 * (ug % (TX / 4)); }
             NDWT_SFOR(e, NE)
-                st.off[k][e] = y * a.n1 + modn(xb + e, a.n1);
+                st.off[k][e] = y * a.rs + modn(xb + e, a.n1);
             NDWT_SEND
         NDWT_SEND
     }
@@ -932,7 +939,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
                     NDWT_SFOR(i, RY)
                         int gy = tc.y0 + yg * RY + i;
                         if (gy < a.n2) {
-                            T* dst = a.out[0] + obase + (long long)z * a.plane + (long long)gy * a.n1 + gx;
+                            T* dst = a.out[0] + obase + (long long)z * a.plane + (long long)gy * a.rs + gx;
                             if constexpr (VEC4 && CH == 2) {
                                 if (gx < a.n1) *reinterpret_cast<v2*>(dst) = v2{st.zacc[k][done][i * CH], st.zacc[k][done][i * CH + CH - 1]};
                             } else {
@@ -957,8 +964,8 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
 
     template <class Exec> static NDWT_DEV void block(Exec& ex, Shared& sh, const Args& a, const Taps& tp, int bid) {
         const TileCoord tc = decode_tile(a, bid, TX, TY);
-        const long long ibase = (long long)tc.batch * a.in_bstride;
-        const long long obase = (long long)tc.batch * a.out_bstride;
+        const long long ibase = batch_base(tc.batch, a.bsplit, a.in_bstride, a.in_bstride2);
+        const long long obase = batch_base(tc.batch, a.bsplit, a.out_bstride, a.out_bstride2);
         const int zsh = tc.batch * a.zbs;
         const int nsteps = tc.zend - tc.zbeg;
         const int nplanes = nsteps + L - 1;              // planes zbeg-LH .. zend-1+RH

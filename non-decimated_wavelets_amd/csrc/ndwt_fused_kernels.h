@@ -65,6 +65,14 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
 #define NDWT_FUSED_KC(KIND, INV, T, LL, V, VEC)                                                              \
     KIND<T, LL, Fused3Tile<T, INV, V>::TX, Fused3Tile<T, INV, V>::TY, Fused3Tile<T, INV, V>::NT,             \
          Fused3Tile<T, INV, V>::RY, VEC, Fused3Tile<T, INV, V>::WPE, 2>
+// x taps stepping over EWV interleaved scalars (EWV = 4: a level dilated by 4)
+#define NDWT_FUSED_KE(KIND, INV, T, LL, V, VEC, EWV)                                                         \
+    KIND<T, LL, Fused3Tile<T, INV, V>::TX, Fused3Tile<T, INV, V>::TY, Fused3Tile<T, INV, V>::NT,             \
+         Fused3Tile<T, INV, V>::RY, VEC, Fused3Tile<T, INV, V>::WPE, EWV>
+#define NDWT_FUSED_CASE_E(KIND, INV, T, LL, V, EWV)                                                          \
+    case LL:                                                                                                 \
+        return vec4 ? launch_fused3<NDWT_FUSED_KE(KIND, INV, T, LL, V, true, EWV)>(a, t, taps_dev, s)        \
+                    : launch_fused3<NDWT_FUSED_KE(KIND, INV, T, LL, V, false, EWV)>(a, t, taps_dev, s);
 #define NDWT_FUSED_CASE_C(KIND, INV, T, LL, V)                                                                \
     case LL:                                                                                                 \
         return vec4 ? launch_fused3<NDWT_FUSED_KC(KIND, INV, T, LL, V, true)>(a, t, taps_dev, s)             \
@@ -97,6 +105,15 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
 // float synthesis: the lane-shift kernel on a tall 64x32 tile (1024 threads, one workgroup per CU) is the default;
 // variant 2 = the same kernel on 64x16 / 256 threads, variant 3 = the LDS kernel (A/B runs, db4 only)
 #define NDWT_FUSED_SWITCH_INV_F32(T)                                      \
+    if (ew == 4) {                                                        \
+        switch (t.Lp) {                                                   \
+            NDWT_FUSED_CASE_E(Inv3S, true, T, 2, 4, 4)                    \
+            NDWT_FUSED_CASE_E(Inv3S, true, T, 4, 4, 4)                    \
+            NDWT_FUSED_CASE_E(Inv3S, true, T, 6, 4, 4)                    \
+            NDWT_FUSED_CASE_E(Inv3S, true, T, 8, 4, 4)                    \
+            default: return -1;                                           \
+        }                                                                 \
+    }                                                                     \
     if (ew == 2) {                                                        \
         switch (t.Lp) {                                                   \
             NDWT_FUSED_CASE_C(Inv3S, true, T, 2, 1)                       \
@@ -143,6 +160,15 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
 // float analysis: 256-thread kernel for tap lengths <= 8, 512 threads (one column per thread) for 10 and 12;
 // variant 2 = tall 64x32 tile with 1024 threads (A/B runs)
 #define NDWT_FUSED_SWITCH_FWD_F32(T)                                      \
+    if (ew == 4) {                                                        \
+        switch (t.Lp) {                                                   \
+            NDWT_FUSED_CASE_E(Fwd3, false, T, 2, 1, 4)                    \
+            NDWT_FUSED_CASE_E(Fwd3, false, T, 4, 1, 4)                    \
+            NDWT_FUSED_CASE_E(Fwd3, false, T, 6, 1, 4)                    \
+            NDWT_FUSED_CASE_E(Fwd3, false, T, 8, 1, 4)                    \
+            default: return -1;                                           \
+        }                                                                 \
+    }                                                                     \
     if (ew == 2) {                                                        \
         switch (t.Lp) {                                                   \
             NDWT_FUSED_CASE_C(Fwd3, false, T, 2, 0)                       \

@@ -18,7 +18,8 @@ inline void fused3_geometry(Fused3Args<T>& a, int TX, int TY, int Lp, int target
                             int many_blocks = 0) {
     a.ntx = (a.n1 + TX - 1) / TX;
     a.nty = (a.n2 + TY - 1) / TY;
-    a.plane = (long long)a.n1 * a.n2;
+    a.plane = (long long)a.n1 * a.n2;             // dense volume; a dilated launch overrides rs / plane afterwards
+    a.rs = a.n1;
     long long per_chunk = (long long)a.ntx * a.nty * a.nbatch;
     int want = (int)(target_blocks / per_chunk);
     if (want < 1) want = many_blocks > 0 ? (int)((many_blocks + per_chunk - 1) / per_chunk) : 1;

@@ -74,11 +74,15 @@ int dispatch(int Lp, int vec4, ndwt::Fused3Args<T>& a, const double* lo, const d
 template <typename T, bool INV>
 int emu3(int Lp, int vec4, const T* in, T* out, int n1, int n2, int n3, int nbatch, int zchunk,
          const double* lo, const double* hi, int z_wrap, int small_tile, int variant, int ew, double shrink_thr, int shrink_mask,
-         int shrink_hard) {
+         int shrink_hard, int dil) {
     ndwt::Fused3Args<T> a;
     std::memset(&a, 0, sizeof(a));
     a.n1 = n1; a.n2 = n2; a.n3 = n3; a.nbatch = nbatch;
     const long long vol = (long long)n1 * n2 * n3;
+    if (dil > 1) {              // a level dilated by `dil` (n2, n3 are the full sizes): one (y, z) sub-lattice per batch item, x by EW = dil
+        a.n2 = n2 / dil; a.n3 = n3 / dil; a.nbatch = dil * dil;
+        ew = dil;
+    }
     const int halo = Lp - 1;
     const long long vol_in = z_wrap ? vol : (long long)n1 * n2 * (n3 + halo);
     a.z_wrap = z_wrap;
@@ -93,28 +97,52 @@ int emu3(int Lp, int vec4, const T* in, T* out, int n1, int n2, int n3, int nbat
         for (int b = 0; b < 8; ++b) a.in[b] = in + b * vol_in * nbatch;
         a.out[0] = out;
     }
+    auto geometry = [&](int TX, int TY) {
+        ndwt::fused3_geometry(a, TX, TY, Lp, 2048, zchunk);
+        if (dil > 1) {
+            a.rs = dil * n1;
+            a.plane = (long long)dil * n1 * n2;
+            a.bsplit = dil;
+            a.in_bstride = a.out_bstride = n1;
+            a.in_bstride2 = a.out_bstride2 = (long long)n1 * n2;
+        }
+    };
     // the tile shapes the library launches
     typedef ndwt::Fused3Tile<T, false, 0> PF;
     typedef ndwt::Fused3Tile<T, true, 0> PI;
     typedef ndwt::Fused3Tile<T, false, 1> PF1;
     typedef ndwt::Fused3Tile<T, true, 1> PI1;   // the default lane-shift synthesis configuration (float and double)
     typedef ndwt::Fused3Tile<T, true, 2> PI2;   // lane-shift synthesis, smaller tile
+    if (ew == 4) {      // level dilated by 4: the library's 512-thread tiles (float only)
+        if constexpr (sizeof(T) == 4) {
+            typedef ndwt::Fused3Tile<T, false, 1> DF;
+            typedef ndwt::Fused3Tile<T, true, 4> DI;
+            if constexpr (INV) {
+                geometry(DI::TX, DI::TY);
+                return dispatch<T, ndwt::Inv3S, DI::TX, DI::TY, DI::NT, DI::RY, false, 4>(Lp, vec4, a, lo, hi);
+            } else {
+                geometry(DF::TX, DF::TY);
+                return dispatch<T, ndwt::Fwd3, DF::TX, DF::TY, DF::NT, DF::RY, false, 4>(Lp, vec4, a, lo, hi);
+            }
+        }
+        return -1;
+    }
     if (ew == 2) {      // interleaved complex: n1 counts scalars; lane-shift synthesis and LDS analysis kernels
         if (small_tile) {
-            ndwt::fused3_geometry(a, 16, 8, Lp, 2048, zchunk);
+            geometry(16, 8);
             if constexpr (INV) return dispatch<T, ndwt::Inv3S, 16, 8, 128, 2, true, 2>(Lp, vec4, a, lo, hi);
             else return dispatch<T, ndwt::Fwd3, 16, 8, 64, 2, true, 2>(Lp, vec4, a, lo, hi);
         }
         if constexpr (INV) {
-            ndwt::fused3_geometry(a, PI1::TX, PI1::TY, Lp, 2048, zchunk);
+            geometry(PI1::TX, PI1::TY);
             return dispatch<T, ndwt::Inv3S, PI1::TX, PI1::TY, PI1::NT, PI1::RY, false, 2>(Lp, vec4, a, lo, hi);
         } else {
-            ndwt::fused3_geometry(a, PF::TX, PF::TY, Lp, 2048, zchunk);
+            geometry(PF::TX, PF::TY);
             return dispatch<T, ndwt::Fwd3, PF::TX, PF::TY, PF::NT, PF::RY, false, 2>(Lp, vec4, a, lo, hi);
         }
     }
     if (small_tile) {   // a second tile shape exercises different item/lane mappings
-        ndwt::fused3_geometry(a, 16, 8, Lp, 2048, zchunk);
+        geometry(16, 8);
         if constexpr (INV) {
             if (variant == 2)   // lane-shift synthesis on the small tile, every tap length
                 return dispatch<T, ndwt::Inv3S, 16, 8, 128, 2, true>(Lp, vec4, a, lo, hi);
@@ -125,21 +153,21 @@ int emu3(int Lp, int vec4, const T* in, T* out, int n1, int n2, int n3, int nbat
     }
     if constexpr (INV) {
         if (variant == 3) {
-            ndwt::fused3_geometry(a, PI2::TX, PI2::TY, Lp, 2048, zchunk);
+            geometry(PI2::TX, PI2::TY);
             return dispatch<T, ndwt::Inv3S, PI2::TX, PI2::TY, PI2::NT, PI2::RY, false>(Lp, vec4, a, lo, hi);
         }
         if (variant == 1) {
-            ndwt::fused3_geometry(a, PI1::TX, PI1::TY, Lp, 2048, zchunk);
+            geometry(PI1::TX, PI1::TY);
             return dispatch<T, ndwt::Inv3S, PI1::TX, PI1::TY, PI1::NT, PI1::RY, false>(Lp, vec4, a, lo, hi);
         }
-        ndwt::fused3_geometry(a, PI::TX, PI::TY, Lp, 2048, zchunk);
+        geometry(PI::TX, PI::TY);
         return dispatch<T, ndwt::Inv3, PI::TX, PI::TY, PI::NT, PI::RY, false>(Lp, vec4, a, lo, hi);
     } else {
         if (variant == 1) {
-            ndwt::fused3_geometry(a, PF1::TX, PF1::TY, Lp, 2048, zchunk);
+            geometry(PF1::TX, PF1::TY);
             return dispatch<T, ndwt::Fwd3, PF1::TX, PF1::TY, PF1::NT, PF1::RY, false>(Lp, vec4, a, lo, hi);
         }
-        ndwt::fused3_geometry(a, PF::TX, PF::TY, Lp, 2048, zchunk);
+        geometry(PF::TX, PF::TY);
         return dispatch<T, ndwt::Fwd3, PF::TX, PF::TY, PF::NT, PF::RY, false>(Lp, vec4, a, lo, hi);
     }
 }
@@ -328,8 +356,8 @@ int ndwt_emu2_f64(int inverse, int Lp, int vec4, const double* in, double* out, 
 // in/out: band-planar, batch inside band: [band][batch][n3(+halo)][n2][n1]; lo/hi: [3][20] padded kernel-form taps
 #define EMU3_ARGS(T) int Lp, int vec4, const T* in, T* out, int n1, int n2, int n3, int nbatch, int zchunk, const double* lo, \
                      const double* hi, int z_wrap, int small_tile, int variant, int ew, double shrink_thr, int shrink_mask, \
-                     int shrink_hard
-#define EMU3_PASS Lp, vec4, in, out, n1, n2, n3, nbatch, zchunk, lo, hi, z_wrap, small_tile, variant, ew, shrink_thr, shrink_mask, shrink_hard
+                     int shrink_hard, int dil
+#define EMU3_PASS Lp, vec4, in, out, n1, n2, n3, nbatch, zchunk, lo, hi, z_wrap, small_tile, variant, ew, shrink_thr, shrink_mask, shrink_hard, dil
 #if EMU_IN(5)
 int ndwt_emu3_f32_fwd(EMU3_ARGS(float)) { return emu3<float, false>(EMU3_PASS); }
 #endif

@@ -29,7 +29,7 @@ def emu():
     return ctypes.CDLL(os.path.join(ROOT, "tests", "emu", target))
 
 
-def _run(emu, x_mat_or_bands, wnames, l2, inverse, dtype, vec4, zchunk, small, z_wrap=1, variant=0, cplx=False, shrink=(0.0, 0, 0)):
+def _run(emu, x_mat_or_bands, wnames, l2, inverse, dtype, vec4, zchunk, small, z_wrap=1, variant=0, cplx=False, shrink=(0.0, 0, 0), dil=1):
     Ls = [len(orc.wave_filters(w)[0]) for w in wnames]
     Lp = max(Ls)
     lo = np.zeros((3, 20))
@@ -52,7 +52,7 @@ def _run(emu, x_mat_or_bands, wnames, l2, inverse, dtype, vec4, zchunk, small, z
     fn.restype = ctypes.c_int
     rc = fn(int(inverse), Lp, int(vec4), src.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p),
             n1, n2, n3, 1, zchunk, lo.ctypes.data_as(ctypes.c_void_p), hi.ctypes.data_as(ctypes.c_void_p), z_wrap,
-            int(small), int(variant), 2 if cplx else 1, ctypes.c_double(shrink[0]), int(shrink[1]), int(shrink[2]))
+            int(small), int(variant), 2 if cplx else 1, ctypes.c_double(shrink[0]), int(shrink[1]), int(shrink[2]), int(dil))
     assert rc == 0
     return np.transpose(out)
 
@@ -313,3 +313,25 @@ def test_emulated_synthesis_with_fused_shrinkage(emu, cplx, hard):
     want = orc.spatial_level_rec(_np_shrink_bands(c, 0.5, hard, 0xE), filt, 1)
     got = _run2(emu, c, wn, 1, True, np.float64, True, 7, cplx=cplx, shrink=(0.5, 0xE, hard))
     assert np.abs(got - want).max() <= 1e-12 * max(np.abs(want).max(), 1.0)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("sizes,wn,dil,dtype", [
+    ((24, 12, 8), ("db4", "db2", "db3"), 2, np.float64),
+    ((72, 16, 6), ("db2", "db4", "db1"), 2, np.float32),
+    ((72, 16, 8), ("db4", "db3", "db2"), 4, np.float32),        # stride 4: the 512-thread tiles, x taps over 4 scalars
+])
+def test_emulated_dilated_level_on_sublattices(emu, sizes, wn, dil, dtype):
+    """an a-trous level (tap stride = dil on every axis) as dil^3 independent stride-1 problems: x through EW = dil,
+    the (y, z) sub-lattices as batch items with strided rows and planes"""
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal(sizes)
+    c = rng.standard_normal(tuple(sizes) + (8,))
+    filt = [orc.wave_filters(w) for w in wn]
+    tol = 1e-13 if dtype == np.float64 else 2e-6
+    want_y = orc.spatial_level_dec(x, filt, 1, dil)
+    got = _run(emu, x, wn, 1, False, dtype, True, 0, False, dil=dil)
+    assert np.isfinite(got).all() and np.abs(got - want_y).max() <= tol * np.abs(want_y).max()
+    want_r = orc.spatial_level_rec(c, filt, 1, dil)
+    got = _run(emu, c, wn, 1, True, dtype, True, 0, False, dil=dil)
+    assert np.isfinite(got).all() and np.abs(got - want_r).max() <= tol * max(np.abs(want_r).max(), 1.0)

@@ -216,6 +216,35 @@ def test_split_complex_entry_points_match_the_interleaved_transform():
         pc.dec_split(tx.data_ptr(), None, ty.data_ptr(), None, lev)
 
 
+@pytest.mark.parametrize("sizes,wn,precision", [
+    ([24, 20, 16], ["db4", "db2", "db3"], "single"),          # every axis divides by 4: levels 2 and 3 run fused on sub-lattices
+    ([72, 40, 32], ["db2", "db2", "db4"], "single"),
+    ([24, 20, 16], ["db3", "db1", "db2"], "double"),          # double: level 2 fused (stride 2), level 3 per axis
+    ([24, 18, 16], ["db2", "db2", "db2"], "single"),          # 18 % 4 != 0: level 3 per axis
+])
+def test_atrous_levels_on_sublattices(sizes, wn, precision):
+    """dilated (a-trous) levels: stride-2 / stride-4 levels run as independent stride-1 problems on the sub-lattices
+    (x taps stepping over 2 / 4 interleaved scalars, (y, z) sub-lattices as batch items with strided rows and planes)"""
+    rng = np.random.default_rng(41)
+    x = rng.standard_normal(sizes)
+    w = ndwt.nd_dwt_3D(wn, sizes, "pres_l2_norm", 1, "precision", precision, "dilation", "atrous")
+    tol = TOL[precision]
+    xg = _colmajor_gpu(x, precision)
+    for level in (2, 3):
+        y = w.dec(xg, level)
+        want = orc.spatial_dec(x, wn, level, 1, "atrous")
+        assert _relerr(y.cpu().numpy(), want) <= tol
+        assert _relerr(w.rec(y).cpu().numpy(), x) <= 20 * tol
+        c = rng.standard_normal(want.shape)
+        got = w.rec(_colmajor_gpu(c, precision)).cpu().numpy()
+        assert _relerr(got, orc.spatial_rec(c, wn, 1, "atrous")) <= 4 * tol
+    # same numbers as the per-axis kernels
+    wg = ndwt.nd_dwt_3D(wn, sizes, "pres_l2_norm", 1, "precision", precision, "dilation", "atrous")
+    plan = wg._plan(False, 3, xg.device)
+    plan.set_path(True)
+    assert _relerr(wg.dec(xg, 3).cpu().numpy(), w.dec(xg, 3).cpu().numpy()) <= tol
+
+
 def _np_shrink(c, t, hard):
     m = np.abs(c)
     with np.errstate(invalid="ignore", divide="ignore"):
