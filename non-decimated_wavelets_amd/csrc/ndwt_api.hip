@@ -294,6 +294,17 @@ static bool fused3_dilated_eligible(const ndwt_plan* p, long long stride, int* L
     return true;
 }
 
+// the 2-D analogue: x through EW = stride, the `stride` row sub-lattices as batch items
+static bool fused2_dilated_eligible(const ndwt_plan* p, long long stride, int* Lp_out) {
+    if (p->path != NDWT_PATH_AUTO || p->ndim != 2 || p->complexity != NDWT_REAL) return false;
+    if (stride != 2 && !(stride == 4 && p->dtype == NDWT_F32)) return false;
+    int Lp = p->filt[0].len > p->filt[1].len ? p->filt[0].len : p->filt[1].len;
+    if (Lp > 8 || p->dims[0] % stride != 0 || p->dims[1] % stride != 0 || p->dims[0] % 4 != 0) return false;
+    if (p->dims[0] >= (1LL << 30) || p->dims[1] >= (1LL << 30)) return false;
+    *Lp_out = Lp;
+    return true;
+}
+
 static bool fused2_eligible(const ndwt_plan* p, long long stride, int* Lp_out) {
     if (p->path != NDWT_PATH_AUTO || stride != 1 || p->ndim != 2) return false;
     int Lp = p->filt[0].len > p->filt[1].len ? p->filt[0].len : p->filt[1].len;
@@ -415,14 +426,14 @@ template <> int launch2<double>(bool inverse, const Fused2Args<double>& a, int L
 // one fused 2-D launch; n2 = output rows; y_wrap=false: inputs carry the y halo (slab mode)
 template <typename T>
 static int fused2_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* in, T* const* out, long long n2, long long in_bstride,
-                      long long out_bstride, bool y_wrap, hipStream_t s) {
+                      long long out_bstride, bool y_wrap, hipStream_t s, int dil = 1) {
     Fused2Args<T> a;
     memset(&a, 0, sizeof a);
     a.n1 = (int)(p->dims[0] * p->comp);
-    a.n2 = (int)n2;
-    a.nbatch = 1;
-    a.in_bstride = in_bstride;
-    a.out_bstride = out_bstride;
+    a.n2 = (int)(n2 / dil);                               // dil > 1: the dil row sub-lattices are the batch items
+    a.nbatch = dil;
+    a.in_bstride = dil > 1 ? p->dims[0] : in_bstride;
+    a.out_bstride = dil > 1 ? p->dims[0] : out_bstride;
     a.y_wrap = y_wrap ? 1 : 0;
     if (inverse && p->shrink_mode) {                     // ndwt_denoise: threshold the 3 detail bands as they are loaded
         a.shrink_thr = (T)p->shrink_thr;
@@ -433,11 +444,13 @@ static int fused2_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     const int nin = inverse ? 4 : 1, nout = inverse ? 1 : 4;
     for (int b = 0; b < nin; ++b) { a.in[b] = in[b]; vec4 = vec4 && aligned_vec4<T>(in[b]); }
     for (int b = 0; b < nout; ++b) { a.out[b] = out[b]; vec4 = vec4 && aligned_vec4<T>(out[b]); }
-    fused2_geometry(a, fused2_tile_width(inverse, Lp, (int)p->comp), Lp, p->target_blocks > 0 ? p->target_blocks * 2 : 2048, p->force_zchunk);   // 8 waves per CU: one round (measured optimum 1024^2 .. 4096^2)
+    const int ew2 = dil > 1 ? dil : (int)p->comp;
+    fused2_geometry(a, fused2_tile_width(inverse, Lp, ew2), Lp, p->target_blocks > 0 ? p->target_blocks * 2 : 2048, p->force_zchunk);
+    if (dil > 1) a.rs = (int)(dil * p->dims[0]);   // 8 waves per CU: one round (measured optimum 1024^2 .. 4096^2)
     const void* td = p->taps_dev[inverse ? 1 : 0];
     if (!td) return fail(NDWT_ERR_UNSUPPORTED, "plan has no device tap table");
     prof_begin(p, inverse ? NDWT_KERNEL_FUSED_SYNTHESIS : NDWT_KERNEL_FUSED_ANALYSIS, s);
-    int rc = launch2<T>(inverse, a, Lp, vec4, (int)p->comp, td, s);
+    int rc = launch2<T>(inverse, a, Lp, vec4, ew2, td, s);
     prof_end(p, s);
     if (rc == -1) return fail(NDWT_ERR_UNSUPPORTED, "no fused 2-D kernel instantiated for tap length %d", Lp);
     if (rc != 0) return fail(NDWT_ERR_HIP, "fused 2-D kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -477,6 +490,10 @@ static int analysis_level(ndwt_plan* p, const T* in, T* const* out, long long st
         rc = fused3_run<T>(p, false, Lp, ins_lo, out, p->dims[2], p->dims[3], vol3, vol3, 1, s);
         if (rc) return rc;
         return fused3_run<T>(p, false, Lp, ins_hi, out + 8, p->dims[2], p->dims[3], vol3, vol3, 1, s);
+    }
+    if (!slab && fused2_dilated_eligible(p, stride, &Lp)) {
+        const T* ins[4] = {in};
+        return fused2_run<T>(p, false, Lp, ins, out, p->dims[1], 0, 0, true, s, (int)stride);
     }
     if (fused2_eligible(p, stride, &Lp) && !(slab && ftop.len != Lp)) {
         const T* ins[4] = {in};
@@ -524,6 +541,10 @@ static int synthesis_level(ndwt_plan* p, const T* const* in, T* out, long long s
         rc = fused3_run<T>(p, true, Lp, in + 8, outs_d, p->dims[2], n_top_in, vol3, vol3, 1, s, 0, LLONG_MIN, 0, 0xFF);   // t-high half: all details
         if (rc) return rc;
         return axis_pass<T>(p, true, 3, p->dims, stride, !slab, a, dd, out, nullptr, s);
+    }
+    if (!slab && fused2_dilated_eligible(p, stride, &Lp)) {
+        T* outs[4] = {out};
+        return fused2_run<T>(p, true, Lp, in, outs, p->dims[1], 0, 0, true, s, (int)stride);
     }
     if (fused2_eligible(p, stride, &Lp) && !(slab && ftop.len != Lp)) {
         T* outs[4] = {out};

@@ -1004,6 +1004,7 @@ template <typename T> struct Fused2Args {
     int ntx, nyc;          // wave tiles along x, chunks along y
     int y_wrap;            // 1: periodic in y; 0: inputs start `left` rows before local row 0 (slab mode)
     int dbg;
+    int rs;                // elements between rows (n1; a level dilated by s: s * n1, the s row sub-lattices are the batch items)
     T shrink_thr;          // synthesis: shrink input band b on load when bit b of shrink_mask is set
     int shrink_mask, shrink_hard;
 };
@@ -1051,7 +1052,7 @@ template <typename T, int L_, bool VEC4_, int WPE_ = 4, int EW_ = 1> struct Fwd2
     }
     static NDWT_DEV void load_row(State& st, const Args& a, const T* inb, int yraw) {
         long long ym = a.y_wrap ? (long long)modn(yraw, a.n2) : (long long)(yraw + LH);
-        const T* p = inb + ym * a.n1;
+        const T* p = inb + ym * a.rs;
         if constexpr (VEC4) {
             st.nxt = *reinterpret_cast<const v4*>(p + st.off[0]);
         } else {
@@ -1110,7 +1111,7 @@ template <typename T, int L_, bool VEC4_, int WPE_ = 4, int EW_ = 1> struct Fwd2
         NDWT_SEND
         int gx = tc.x0 + 4 * (tid - GL);
         if (tid < GL || tid >= 64 - GR || gx >= a.n1) return;
-        long long off = obase + (long long)y * a.n1 + gx;
+        long long off = obase + (long long)y * a.rs + gx;
         v4 o0 = {xlo[0].x, xlo[1].x, xlo[2].x, xlo[3].x}, o1 = {xhi[0].x, xhi[1].x, xhi[2].x, xhi[3].x};
         v4 o2 = {xlo[0].y, xlo[1].y, xlo[2].y, xlo[3].y}, o3 = {xhi[0].y, xhi[1].y, xhi[2].y, xhi[3].y};
         if constexpr (VEC4) {
@@ -1173,7 +1174,7 @@ template <typename T, int L_, bool VEC4_, int WPE_ = 4, int EW_ = 1> struct Inv2
     static NDWT_DEV void load_row(State& st, const Args& a, long long ibase, int yraw) {
         long long ym = a.y_wrap ? (long long)modn(yraw, a.n2) : (long long)(yraw + LH);
         NDWT_SFOR(b, 4)
-            const T* p = a.in[b] + ibase + ym * a.n1;
+            const T* p = a.in[b] + ibase + ym * a.rs;
             if constexpr (VEC4) {
                 st.raw[b] = *reinterpret_cast<const v4*>(p + st.off[0]);
             } else {
@@ -1226,7 +1227,7 @@ template <typename T, int L_, bool VEC4_, int WPE_ = 4, int EW_ = 1> struct Inv2
         constexpr int done = ((R - L) % L + L) % L;
         int gx = tc.x0 + 4 * (tid - GL);
         if (tid < GL || tid >= 64 - GR || gx >= a.n1) return;
-        long long off = obase + (long long)y * a.n1 + gx;
+        long long off = obase + (long long)y * a.rs + gx;
         if constexpr (VEC4) {
             *reinterpret_cast<v4*>(a.out[0] + off) = v4{st.yacc[done][0], st.yacc[done][1], st.yacc[done][2], st.yacc[done][3]};
         } else {

@@ -42,6 +42,11 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
 
 #define NDWT_FUSED2_CASE(KIND, T, LL)                                                        \
     case LL:                                                                                 \
+        if constexpr (sizeof(T) == 4 && LL <= 8) {   /* a level dilated by 4: x taps over 4 scalars (float, db1..db4) */ \
+            if (ew == 4)                                                                     \
+                return vec4 ? launch_fused2<KIND<T, LL, true, 4, 4>>(a, taps_dev, s) : launch_fused2<KIND<T, LL, false, 4, 4>>(a, taps_dev, s); \
+        }                                                                                    \
+        if (ew == 4) return -1;                                                              \
         if (ew == 2)                                                                         \
             return vec4 ? launch_fused2<KIND<T, LL, true, (sizeof(T) == 8 ? 2 : 4), 2>>(a, taps_dev, s)   \
                         : launch_fused2<KIND<T, LL, false, (sizeof(T) == 8 ? 2 : 4), 2>>(a, taps_dev, s); \

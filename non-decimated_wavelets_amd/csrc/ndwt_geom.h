@@ -49,6 +49,7 @@ inline bool fused3_fits(long long n1, long long n2, long long n3, long long nbat
 template <typename T>
 inline void fused2_geometry(Fused2Args<T>& a, int WX, int Lp, int target_waves = 4096, int force_ychunk = 0) {
     a.ntx = (a.n1 + WX - 1) / WX;
+    a.rs = a.n1;                                  // dense image; a dilated launch overrides it afterwards
     long long per_chunk = (long long)a.ntx * a.nbatch;
     int want = (int)((target_waves + per_chunk - 1) / per_chunk);
     if (want < 1) want = 1;

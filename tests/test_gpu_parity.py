@@ -245,6 +245,28 @@ def test_atrous_levels_on_sublattices(sizes, wn, precision):
     assert _relerr(wg.dec(xg, 3).cpu().numpy(), w.dec(xg, 3).cpu().numpy()) <= tol
 
 
+@pytest.mark.parametrize("sizes,wn,precision", [
+    ([72, 40], ["db4", "db2"], "single"),        # both axes divide by 4: levels 2 and 3 fused on sub-lattices
+    ([264, 36], ["db3", "db4"], "single"),       # two wave tiles along x
+    ([72, 40], ["db2", "db3"], "double"),        # double: stride 2 fused, stride 4 per axis
+    ([72, 42], ["db2", "db2"], "single"),        # 42 % 4 != 0: level 3 per axis
+])
+def test_atrous_levels_on_sublattices_2d(sizes, wn, precision):
+    rng = np.random.default_rng(43)
+    x = rng.standard_normal(sizes)
+    w = ndwt.nd_dwt_2D(wn, sizes, "pres_l2_norm", 0, "precision", precision, "dilation", "atrous")
+    tol = TOL[precision]
+    xg = _colmajor_gpu(x, precision)
+    for level in (2, 3):
+        y = w.dec(xg, level)
+        want = orc.spatial_dec(x, wn, level, 0, "atrous")
+        assert _relerr(y.cpu().numpy(), want) <= tol
+        assert _relerr(w.rec(y).cpu().numpy(), x) <= 20 * tol
+        c = rng.standard_normal(want.shape)
+        got = w.rec(_colmajor_gpu(c, precision)).cpu().numpy()
+        assert _relerr(got, orc.spatial_rec(c, wn, 0, "atrous")) <= 4 * tol
+
+
 def _np_shrink(c, t, hard):
     m = np.abs(c)
     with np.errstate(invalid="ignore", divide="ignore"):
