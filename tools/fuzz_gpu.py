@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU: random dimensions (primes, sizes below one tile, non-multiples of 4), mixed
 db1..db10 wavelets, levels, precisions, real / complex, both dilations, against the CPU oracle.  Not part of the test
-suite (minutes of oracle time); run it after kernel changes:  python tools/fuzz_gpu.py [cases] [seed] [max_order]   (max_order <= 4 keeps every case
-on the fused kernels)"""
+suite (minutes of oracle time); run it after kernel changes:  python tools/fuzz_gpu.py [cases] [seed] [max_order] [p_atrous]   (max_order <= 4 keeps every
+case on the fused kernels)"""
 import os
 import sys
 
@@ -18,6 +18,7 @@ import ndwt_oracle as orc  # noqa: E402
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 max_order = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+p_atrous = float(sys.argv[4]) if len(sys.argv) > 4 else 0.2
 CLS = {1: ndwt.nd_dwt_1D, 2: ndwt.nd_dwt_2D, 3: ndwt.nd_dwt_3D, 4: ndwt.nd_dwt_4D}
 TOL = {"double": 1e-12, "single": 3e-6}
 worst = 0.0
@@ -29,10 +30,12 @@ for k in range(cases):
     if rng.random() < 0.3:
         sizes[0] = int(rng.choice([64, 68, 72, 128, 132])) if d <= 3 else sizes[0]      # whole tiles / ragged tiles
     level = int(rng.integers(1, 4))
-    dilation = "atrous" if rng.random() < 0.2 else "reference"
+    dilation = "atrous" if rng.random() < p_atrous else "reference"
     if dilation == "atrous":                                     # dilated filters (the plan is built for 3 levels) must fit the axis
         orders = [min(o, 3 if d < 4 else 2) for o in orders]
         sizes = [max(s, 2 * o * 4) for s, o in zip(sizes, orders)]
+        if rng.random() < 0.7:                                   # axes that divide by 4: the dilated levels run fused on sub-lattices
+            sizes = [4 * ((s + 3) // 4) for s in sizes]
     l2 = int(rng.integers(0, 2))
     precision = "single" if rng.random() < 0.5 else "double"
     cplx = rng.random() < 0.4
