@@ -489,17 +489,18 @@ def _two_rank_worker(rank, world, port, q):
         dev = torch.device("cuda", 0)
         torch.manual_seed(5)
         xs = torch.randn(n3, n2, n1, device=dev)               # same volume on every rank
-        w = ndwt.nd_dwt_3D("db4", [n1, n2, n3], "pres_l2_norm", 1, "precision", "single")
-        yref = w.dec(xs.permute(2, 1, 0), level).permute(3, 2, 1, 0)
         errs = []
-        for overlap in (True, False):
-            eng = sh.ShardedNdDwt(["db4"] * 3, [n1, n2, n3], pres_l2_norm=True, precision="single", device=dev, overlap=overlap)
-            assert eng.scheme == "scatter" and eng.overlap == overlap and eng._host_stage
-            yl = eng.dec(xs[eng.z0:eng.z1].contiguous(), level)
-            e_dec = float((yl - yref[:, eng.z0:eng.z1]).abs().max() / yref.abs().max())
-            xl = eng.rec(yl)
-            e_rec = float((xl - xs[eng.z0:eng.z1]).abs().max())
-            errs.append((e_dec, e_rec))
+        for wname in ("db4", "db6", "db1"):                    # db6: cfg4's wavelet (halo 5 + 6 planes); db1: no plane before the slab
+            w = ndwt.nd_dwt_3D(wname, [n1, n2, n3], "pres_l2_norm", 1, "precision", "single")
+            yref = w.dec(xs.permute(2, 1, 0), level).permute(3, 2, 1, 0)
+            for overlap in (True, False):
+                eng = sh.ShardedNdDwt([wname] * 3, [n1, n2, n3], pres_l2_norm=True, precision="single", device=dev, overlap=overlap)
+                assert eng.scheme == "scatter" and eng.overlap == overlap and eng._host_stage
+                yl = eng.dec(xs[eng.z0:eng.z1].contiguous(), level)
+                e_dec = float((yl - yref[:, eng.z0:eng.z1]).abs().max() / yref.abs().max())
+                xl = eng.rec(yl)
+                e_rec = float((xl - xs[eng.z0:eng.z1]).abs().max())
+                errs.append((e_dec, e_rec))
         q.put((rank, errs))
     finally:
         dist.destroy_process_group()
