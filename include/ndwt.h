@@ -135,7 +135,8 @@ int ndwt_synthesis_level_slab(ndwt_plan* plan, const void* const* in_bands_with_
  * analysis reads the local slab and the two halo buffers (as received from the neighbours) from separate pointers;
  * synthesis treats the local coefficient slab as zero outside and writes syn_after + local + syn_before planes:
  * the local result plus the partial sums owed to the neighbouring slabs (they are sent there and added -- 1 band of
- * exchange instead of the halo of all 2^d bands). */
+ * exchange instead of the halo of all 2^d bands).  The zero-extended synthesis also takes 4-D plans sharded on t (16 bands:
+ * the 3-D part runs per frame, the t-axis pass over zero-padded frames). */
 int ndwt_analysis_level_slab_split(ndwt_plan* plan, const void* in_local, const void* halo_before, const void* halo_after,
                                    void* const* out_bands, int stride, void* stream);
 int ndwt_synthesis_level_slab_ext(ndwt_plan* plan, const void* const* in_bands_local, void* out_ext, int stride, void* stream);

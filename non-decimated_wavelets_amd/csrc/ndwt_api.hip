@@ -702,6 +702,34 @@ template <typename T> static int shrink_impl(ndwt_plan* p, T* y, int level, doub
     return NDWT_OK;
 }
 
+// 4-D slab, zero-extended synthesis (scatter scheme of the t-sharded driver): the 3-D part is local to every frame, so
+// the 16 bands of the slab are synthesised to the two t-bands (a, d) for the local frames only, in buffers that carry
+// L-1 zero frames on each side; the t-axis pass over them yields the n_local + L-1 frames of the zero-extended result.
+template <typename T> static int slab_ext4_impl(ndwt_plan* p, int Lp, const void* const* in, void* out, hipStream_t s) {
+    const long long vol3 = p->comp * p->dims[0] * p->dims[1] * p->dims[2];
+    const long long n = p->dims[3], h = p->filt[3].len - 1;
+    const long long nin = n + 2 * h, nout = n + h;
+    int rc = ensure_tmp(p, (size_t)(2 * nin * vol3) * sizeof(T));
+    if (rc) return rc;
+    T* a = (T*)p->tmp;
+    T* dd = a + nin * vol3;
+    for (T* b : {a, dd}) {
+        HIP_TRY(hipMemsetAsync(b, 0, (size_t)(h * vol3) * sizeof(T), s));
+        HIP_TRY(hipMemsetAsync(b + (h + n) * vol3, 0, (size_t)(h * vol3) * sizeof(T), s));
+    }
+    const T* const* inT = (const T* const*)in;
+    T* outs_a[8] = {a + h * vol3};
+    T* outs_d[8] = {dd + h * vol3};
+    rc = fused3_run<T>(p, true, Lp, inT, outs_a, p->dims[2], n, vol3, vol3, 1, s, 0, LLONG_MIN, 0, 0xFE);
+    if (rc) return rc;
+    rc = fused3_run<T>(p, true, Lp, inT + 8, outs_d, p->dims[2], n, vol3, vol3, 1, s, 0, LLONG_MIN, 0, 0xFF);
+    if (rc) return rc;
+    long long dims_ext[NDWT_MAX_DIMS];
+    for (int k = 0; k < 4; ++k) dims_ext[k] = p->dims[k];
+    dims_ext[3] = nout;                                  // outputs; the pass reads nout + L-1 = nin frames (slab mode)
+    return axis_pass<T>(p, true, 3, dims_ext, 1, false, a, dd, (T*)out, nullptr, s);
+}
+
 // a run of output planes of the slab transform (the caller offsets the pointers): what lets the halo exchange
 // overlap with the planes that do not depend on it
 template <typename T>
@@ -1124,6 +1152,14 @@ int ndwt_analysis_level_slab_split(ndwt_plan* p, const void* in_local, const voi
 
 int ndwt_synthesis_level_slab_ext(ndwt_plan* p, const void* const* in_local, void* out_ext, int stride, void* stream) {
     int Lp = 0;
+    if (p && p->ndim == 4) {                             // t-sharded 4-D: 3-D part per frame, zero-extended t-axis pass
+        if (stride != 1 || !fused3_eligible(p, 1, &Lp))
+            return fail(NDWT_ERR_UNSUPPORTED, "the zero-extended 4-D slab synthesis needs a plan on the fused 3-D kernels (stride 1)");
+        if (!in_local || !out_ext) return fail(NDWT_ERR_INVALID_ARG, "null pointer");
+        HIP_TRY(hipSetDevice(p->device));
+        return p->dtype == NDWT_F32 ? slab_ext4_impl<float>(p, Lp, in_local, out_ext, (hipStream_t)stream)
+                                    : slab_ext4_impl<double>(p, Lp, in_local, out_ext, (hipStream_t)stream);
+    }
     int rc = slab_fast_ok(p, stride, &Lp);
     if (rc) return rc;
     if (!in_local || !out_ext) return fail(NDWT_ERR_INVALID_ARG, "null pointer");

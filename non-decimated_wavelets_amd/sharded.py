@@ -45,8 +45,13 @@ class HipSlabEngine:
         self.local_dims = list(local_dims)
         # split-halo analysis + zero-extended synthesis entry points (fused 3-D kernels only)
         lens = [len(L.wave_filters(w)[0]) for w in wnames]
-        self.supports_scatter = (dilation == "reference" and len(local_dims) == 3 and self.plan.describe() == "fused3d"
-                                 and lens[2] == max(lens))
+        # copy-free analysis (separate halo buffers), run-of-planes pieces: fused 3-D plans only
+        self.supports_split = (dilation == "reference" and len(local_dims) == 3 and self.plan.describe() == "fused3d"
+                               and lens[2] == max(lens))
+        self.supports_overlap = self.supports_split
+        # zero-extended synthesis (scatter-add exchange of 1 band): also 4-D plans sharded on t (3-D part per frame)
+        self.supports_scatter = self.supports_split or (dilation == "reference" and len(local_dims) == 4
+                                                        and self.plan.describe() == "axis+fused3d")
 
     def halo(self, stride):
         return self.plan.slab_halo(stride)
@@ -137,7 +142,7 @@ class ShardedNdDwt:
         self._host_stage = bool(self.device.type == "cuda" and dist.is_initialized() and dist.get_backend(group) == "gloo")
         # overlap of the exchange with the planes that do not depend on it needs the run-of-planes entry points
         self.overlap = bool(overlap and self.scheme == "scatter" and hasattr(self.engine, "analysis_run")
-                            and hasattr(self.engine, "synthesis_part"))
+                            and hasattr(self.engine, "synthesis_part") and getattr(self.engine, "supports_overlap", True))
 
     # ---------------------------------------------------------------------------------- plumbing
     def _owner(self, g):
@@ -305,7 +310,8 @@ class ShardedNdDwt:
                     self.engine.analysis_run(cur, hb, ha, outs, n - aa, n, s)
             else:
                 hb, ha = self._fetch_halo(cur, 0, ab, aa)
-                if hasattr(self.engine, "analysis_split") and getattr(self.engine, "supports_scatter", False):
+                if hasattr(self.engine, "analysis_split") and getattr(self.engine, "supports_split",
+                                                                      getattr(self.engine, "supports_scatter", False)):
                     self.engine.analysis_split(cur, hb, ha, outs, s)
                 else:
                     self.engine.analysis(torch.cat([hb, cur, ha], 0), outs, s)

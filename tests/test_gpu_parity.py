@@ -506,6 +506,59 @@ def _two_rank_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _t_sharded_worker(rank, world, port, q):
+    """4-D volume sharded on t (cfg5's decomposition): scatter-add synthesis through the zero-extended 4-D entry point"""
+    import importlib
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sh = importlib.import_module("non-decimated_wavelets_amd.sharded")
+        sizes, level = [24, 20, 12, 18], 2                     # t = 18 frames over 2 ranks: 9 each, halo 3 + 4
+        dev = torch.device("cuda", 0)
+        torch.manual_seed(9)
+        xs = torch.randn(*reversed(sizes), device=dev)
+        w = ndwt.nd_dwt_4D("db4", sizes, "pres_l2_norm", 1, "precision", "single")
+        yref = w.dec(xs.permute(3, 2, 1, 0), level).permute(4, 3, 2, 1, 0)
+        eng = sh.ShardedNdDwt(["db4"] * 4, sizes, pres_l2_norm=True, precision="single", device=dev)
+        assert eng.scheme == "scatter" and not eng.overlap
+        yl = eng.dec(xs[eng.z0:eng.z1].contiguous(), level)
+        e_dec = float((yl - yref[:, eng.z0:eng.z1]).abs().max() / yref.abs().max())
+        e_rec = float((eng.rec(yl) - xs[eng.z0:eng.z1]).abs().max())
+        c = torch.randn_like(yref)
+        want = w.rec(c.permute(4, 3, 2, 1, 0)).permute(3, 2, 1, 0)
+        e_rec2 = float((eng.rec(c[:, eng.z0:eng.z1].contiguous()) - want[eng.z0:eng.z1]).abs().max() / want.abs().max())
+        q.put((rank, [(e_dec, e_rec), (e_rec2, 0.0)]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_ranks(worker, world):
+    import socket
+    import torch.multiprocessing as mp
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_t_sharded_4d_scatter_over_gloo():
+    for rank, errs in _run_ranks(_t_sharded_worker, 2):
+        for e_a, e_b in errs:
+            assert e_a <= 4e-6 and e_b <= 1e-5, (rank, errs)
+
+
 def test_three_ranks_share_one_gpu_over_gloo():
     """the product slab engine (HIP kernels, run-of-planes entry points, in-place halo margins) under a real
     multi-process exchange: 3 processes on cuda:0, gloo with host staging standing in for RCCL"""
