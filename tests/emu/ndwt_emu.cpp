@@ -188,17 +188,25 @@ template <class K, typename T> int run2(ndwt::Fused2Args<T>& a, const double* lo
     return 0;
 }
 
+#define EMU2_GEOM(a, ...)                    \
+    do {                                     \
+        ndwt::fused2_geometry(a, __VA_ARGS__); \
+        if (dil > 1) a.rs = dil * n1;        \
+    } while (0)
+
 template <typename T>
 int emu2(int inverse, int Lp, int vec4, const T* in, T* out, int n1, int n2, int ychunk, const double* lo, const double* hi,
-         int y_wrap, int ew, double shrink_thr, int shrink_mask, int shrink_hard) {
+         int y_wrap, int ew, double shrink_thr, int shrink_mask, int shrink_hard, int dil) {
     ndwt::Fused2Args<T> a;
     std::memset(&a, 0, sizeof(a));
     a.n1 = n1; a.n2 = n2; a.nbatch = 1;
+    if (dil > 1) { a.n2 = n2 / dil; a.nbatch = dil; ew = dil; }     // a level dilated by dil: row sub-lattices as batch items, x by EW
     const long long vol = (long long)n1 * n2;
     const long long vol_in = y_wrap ? vol : (long long)n1 * (n2 + Lp - 1);
     a.y_wrap = y_wrap;
     if (inverse) { a.shrink_thr = (T)shrink_thr; a.shrink_mask = shrink_mask; a.shrink_hard = shrink_hard; }
     a.in_bstride = vol_in; a.out_bstride = vol;
+    if (dil > 1) a.in_bstride = a.out_bstride = n1;
     if (!inverse) {
         a.in[0] = in;
         for (int b = 0; b < 4; ++b) a.out[b] = out + b * vol;
@@ -209,10 +217,10 @@ int emu2(int inverse, int Lp, int vec4, const T* in, T* out, int n1, int n2, int
 #define CASE2C(LL)                                                                                                            \
     case LL:                                                                                                                  \
         if (inverse) {                                                                                                        \
-            ndwt::fused2_geometry(a, ndwt::Inv2S<T, LL, true, 4, 2>::WX, Lp, 64, ychunk);                                      \
+            EMU2_GEOM(a, ndwt::Inv2S<T, LL, true, 4, 2>::WX, Lp, 64, ychunk);                                      \
             return vec4 ? run2<ndwt::Inv2S<T, LL, true, 4, 2>, T>(a, lo, hi) : run2<ndwt::Inv2S<T, LL, false, 4, 2>, T>(a, lo, hi); \
         } else {                                                                                                              \
-            ndwt::fused2_geometry(a, ndwt::Fwd2S<T, LL, true, 4, 2>::WX, Lp, 64, ychunk);                                      \
+            EMU2_GEOM(a, ndwt::Fwd2S<T, LL, true, 4, 2>::WX, Lp, 64, ychunk);                                      \
             return vec4 ? run2<ndwt::Fwd2S<T, LL, true, 4, 2>, T>(a, lo, hi) : run2<ndwt::Fwd2S<T, LL, false, 4, 2>, T>(a, lo, hi); \
         }
     if (ew == 2) {
@@ -225,10 +233,10 @@ int emu2(int inverse, int Lp, int vec4, const T* in, T* out, int n1, int n2, int
 #define CASE2(LL)                                                                                                       \
     case LL:                                                                                                            \
         if (inverse) {                                                                                                  \
-            ndwt::fused2_geometry(a, ndwt::Inv2S<T, LL, true>::WX, Lp, 64, ychunk);                                      \
+            EMU2_GEOM(a, ndwt::Inv2S<T, LL, true>::WX, Lp, 64, ychunk);                                      \
             return vec4 ? run2<ndwt::Inv2S<T, LL, true>, T>(a, lo, hi) : run2<ndwt::Inv2S<T, LL, false>, T>(a, lo, hi); \
         } else {                                                                                                        \
-            ndwt::fused2_geometry(a, ndwt::Fwd2S<T, LL, true>::WX, Lp, 64, ychunk);                                      \
+            EMU2_GEOM(a, ndwt::Fwd2S<T, LL, true>::WX, Lp, 64, ychunk);                                      \
             return vec4 ? run2<ndwt::Fwd2S<T, LL, true>, T>(a, lo, hi) : run2<ndwt::Fwd2S<T, LL, false>, T>(a, lo, hi); \
         }
     switch (Lp) {
@@ -343,14 +351,14 @@ int ndwt_emu_march_f64(int syn, int L, const double* in0, const double* in1, dou
 #endif
 #if EMU_IN(3)
 int ndwt_emu2_f32(int inverse, int Lp, int vec4, const float* in, float* out, int n1, int n2, int ychunk, const double* lo,
-                  const double* hi, int y_wrap, int ew, double shrink_thr, int shrink_mask, int shrink_hard) {
-    return emu2<float>(inverse, Lp, vec4, in, out, n1, n2, ychunk, lo, hi, y_wrap, ew, shrink_thr, shrink_mask, shrink_hard);
+                  const double* hi, int y_wrap, int ew, double shrink_thr, int shrink_mask, int shrink_hard, int dil) {
+    return emu2<float>(inverse, Lp, vec4, in, out, n1, n2, ychunk, lo, hi, y_wrap, ew, shrink_thr, shrink_mask, shrink_hard, dil);
 }
 #endif
 #if EMU_IN(4)
 int ndwt_emu2_f64(int inverse, int Lp, int vec4, const double* in, double* out, int n1, int n2, int ychunk, const double* lo,
-                  const double* hi, int y_wrap, int ew, double shrink_thr, int shrink_mask, int shrink_hard) {
-    return emu2<double>(inverse, Lp, vec4, in, out, n1, n2, ychunk, lo, hi, y_wrap, ew, shrink_thr, shrink_mask, shrink_hard);
+                  const double* hi, int y_wrap, int ew, double shrink_thr, int shrink_mask, int shrink_hard, int dil) {
+    return emu2<double>(inverse, Lp, vec4, in, out, n1, n2, ychunk, lo, hi, y_wrap, ew, shrink_thr, shrink_mask, shrink_hard, dil);
 }
 #endif
 // in/out: band-planar, batch inside band: [band][batch][n3(+halo)][n2][n1]; lo/hi: [3][20] padded kernel-form taps

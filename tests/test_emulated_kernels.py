@@ -100,7 +100,7 @@ def test_emulated_fused3_synthesis(emu, sizes, wn, vec4, zchunk, small, l2):
             assert np.abs(got - want).max() <= tol * max(np.abs(want).max(), 1.0)
 
 
-def _run2(emu, arr, wnames, l2, inverse, dtype, vec4, ychunk, cplx=False, shrink=(0.0, 0, 0)):
+def _run2(emu, arr, wnames, l2, inverse, dtype, vec4, ychunk, cplx=False, shrink=(0.0, 0, 0), dil=1):
     Ls = [len(orc.wave_filters(w)[0]) for w in wnames]
     Lp = max(Ls)
     lo = np.zeros((3, 20))
@@ -123,7 +123,7 @@ def _run2(emu, arr, wnames, l2, inverse, dtype, vec4, ychunk, cplx=False, shrink
     fn.restype = ctypes.c_int
     rc = fn(int(inverse), Lp, int(vec4), src.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), n1, n2, ychunk,
             lo.ctypes.data_as(ctypes.c_void_p), hi.ctypes.data_as(ctypes.c_void_p), 1, 2 if cplx else 1, ctypes.c_double(shrink[0]),
-            int(shrink[1]), int(shrink[2]))
+            int(shrink[1]), int(shrink[2]), int(dil))
     assert rc == 0
     return np.transpose(out)
 
@@ -334,4 +334,21 @@ def test_emulated_dilated_level_on_sublattices(emu, sizes, wn, dil, dtype):
     assert np.isfinite(got).all() and np.abs(got - want_y).max() <= tol * np.abs(want_y).max()
     want_r = orc.spatial_level_rec(c, filt, 1, dil)
     got = _run(emu, c, wn, 1, True, dtype, True, 0, False, dil=dil)
+    assert np.isfinite(got).all() and np.abs(got - want_r).max() <= tol * max(np.abs(want_r).max(), 1.0)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("sizes,wn,dtype", [((72, 20), ("db4", "db2"), np.float64), ((264, 14), ("db2", "db4"), np.float32)])
+def test_emulated_dilated_2d_level_on_row_sublattices(emu, sizes, wn, dtype):
+    """2-D a-trous level with tap stride 2: x through EW = 2, the two row sub-lattices as batch items (row stride 2*n1)"""
+    rng = np.random.default_rng(23)
+    x = rng.standard_normal(sizes)
+    c = rng.standard_normal(tuple(sizes) + (4,))
+    filt = [orc.wave_filters(w) for w in wn]
+    tol = 1e-13 if dtype == np.float64 else 2e-6
+    want_y = orc.spatial_level_dec(x, filt, 0, 2)
+    got = _run2(emu, x, wn, 0, False, dtype, True, 0, dil=2)
+    assert np.isfinite(got).all() and np.abs(got - want_y).max() <= tol * np.abs(want_y).max()
+    want_r = orc.spatial_level_rec(c, filt, 0, 2)
+    got = _run2(emu, c, wn, 0, True, dtype, True, 5, dil=2)
     assert np.isfinite(got).all() and np.abs(got - want_r).max() <= tol * max(np.abs(want_r).max(), 1.0)
