@@ -343,7 +343,7 @@ void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int
     (void)Lp;
     *TX = 64;
     *TY = f64 ? 8 : 16;
-    if (!f64 && inverse && !((variant == 2 || variant == 3) && Lp == 8)) *TY = 32;   // float synthesis default: tall tile
+    if (!f64 && inverse && !(variant == 3 && Lp == 8)) *TY = 32;   // float synthesis default: tall tile
     if (!f64 && !inverse && variant == 2 && (Lp == 8 || Lp == 12)) *TY = 32;
     if (!f64 && inverse && dil == 4) *TY = 16;                                         // x taps over 4 scalars: 64x16 / 512 threads
     if (f64 && !inverse && Lp >= 10) *TY = 16;                                         // double analysis, db5/db6: 512 threads
@@ -384,7 +384,7 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     // One round of workgroups that all fit on the chip at once beats several partial rounds (measured, 512^3 float
     // analysis: 512 workgroups 0.88 ms, 1024: 1.09 ms, 2048: 0.99 ms; 256^3 double synthesis: 256 workgroups 0.36 ms,
     // 640: 0.48 ms).  Workgroups per CU: synthesis 1 (1024 threads / 94 KB of LDS), analysis 2 (3 fit, 2 run faster).
-    const bool small_inv = inverse && sizeof(T) == 4 && (variant == 2 || variant == 3) && Lp == 8;   // 256-thread A/B variants
+    const bool small_inv = inverse && sizeof(T) == 4 && variant == 3 && Lp == 8;   // 256-thread A/B variant
     const int per_cu = inverse ? (small_inv ? 3 : 1) : (dil == 4 ? 1 : 2);
     const int target = p->target_blocks > 0 ? p->target_blocks : p->num_cus * per_cu;
     // analysis (2-3 workgroups per CU): more tiles than resident slots -> about 8 workgroups per CU; synthesis (1 per CU,

@@ -14,7 +14,7 @@ template <> struct Fused3Tile<float, false, 3> { static constexpr int TX = 64, T
 // float, synthesis
 template <> struct Fused3Tile<float, true, 0>  { static constexpr int TX = 64, TY = 16, NT = 256, RY = 2, WPE = 2; };
 template <> struct Fused3Tile<float, true, 1>  { static constexpr int TX = 64, TY = 32, NT = 1024, RY = 1, WPE = 4; };  // lane-shift kernel (Inv3S), tall tile: the float default
-template <> struct Fused3Tile<float, true, 2>  { static constexpr int TX = 64, TY = 16, NT = 256, RY = 2, WPE = 3; };   // lane-shift kernel (Inv3S), 64x16 tile, for A/B runs
+template <> struct Fused3Tile<float, true, 2>  { static constexpr int TX = 64, TY = 32, NT = 512, RY = 1, WPE = 2; };   // lane-shift kernel, tall tile, 512 threads x 2 items: long filters (no spills)
 template <> struct Fused3Tile<float, true, 3>  { static constexpr int TX = 64, TY = 16, NT = 256, RY = 2, WPE = 2; };   // LDS kernel (Inv3), for A/B runs
 // float synthesis of a level dilated by 4 (x taps step over 4 scalars: 23 lanes per haloed row, 2 rows per wave, a 32-value
 // x window): 512 threads with the 256-register budget, two rounds of rows
