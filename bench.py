@@ -1,31 +1,71 @@
 #!/usr/bin/env python3
 """bench.py -- fwd+inv NDWT throughput on MI355X (BASELINE.json metric), one JSON line on rank 0.
 
-Workload at N=1: BASELINE config 3 -- 3-D fp32 512x512x512, db4, 3 levels, reference-parity dilation
-(stride-1 taps at every level, what the reference computes), pres_l2_norm on, synthetic N(0,1) input resident
-in HBM.  A step = dec(x, 3) followed by rec(y).  N>1: the same 512^3 volume sharded on the outermost axis
-(strong scaling), periodic halo exchange per level through torch.distributed (RCCL).
+Workload at N=1 (default): BASELINE config 3 -- 3-D fp32 512x512x512, db4, 3 levels, reference-parity dilation
+(stride-1 taps at every level, what the reference computes), pres_l2_norm on, synthetic N(0,1) input resident in HBM.
+A step = dec(x, level) followed by rec(y).  N>1: the same volume sharded on the outermost axis (strong scaling),
+periodic halo exchange per level through torch.distributed (RCCL).  `--ndim 4` runs BASELINE config 5's transform
+(256x256x256x32, t-sharded for N>1); `--wname db6 --level 4` config 4's.
 
-Algorithmic bytes: each level-direction launch moves (1 + 2^d) V sizeof(T) = 36 B/voxel;
-fwd+inv over 3 levels = 216 B/voxel.
+Launch: `python bench.py --gpus N` starts its own N ranks (one child `torch.distributed.run` process, spawned before
+anything touches the GPU) unless it is already running under a launcher (WORLD_SIZE set).
+
+Algorithmic bytes: a level-direction moves (1 + 2^d) V sizeof(T); fwd+inv over L levels =
+2 L (1 + 2^d) V sizeof(T) (3-D fp32 3 levels: 216 B/voxel).  The dominant kernel's roofline figure uses that kernel's own
+algorithmic bytes per launch: fused 3-D level (1 + 8) V 4 B, one-axis pass (1 + 2) V 4 B.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
-
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s is the measured copy ceiling)
+KERNEL_NAMES = {0: "fused_analysis", 1: "fused_synthesis", 2: "axis_analysis", 3: "axis_synthesis"}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--ndim", type=int, default=3, choices=[3, 4])
+    ap.add_argument("--size", type=int, nargs="+", default=None, help="n1 n2 n3 [n4]; default 512^3 / 256^3 x 32")
+    ap.add_argument("--wname", default="db4")
+    ap.add_argument("--level", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--generic", action="store_true", help="force the per-axis kernels (for comparison)")
+    ap.add_argument("--zchunk", type=int, default=0)
+    ap.add_argument("--target-blocks", type=int, default=0)
+    a = ap.parse_args()
+    if a.size is None:
+        a.size = [512, 512, 512] if a.ndim == 3 else [256, 256, 256, 32]
+    if len(a.size) != a.ndim:
+        ap.error(f"--size needs {a.ndim} numbers")
+    return a
+
+
+def self_launch(a):
+    """No launcher around us and --gpus N > 1: start the N ranks as ONE child process tree (torch.distributed.run) and relay
+    its output.  Nothing in this process has touched the GPU (torch is not even imported yet)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd)
+    sys.exit(r.returncode)
 
 
 def cpu_baseline(level, wname, sample_sizes, workers):
     """The reference's algorithm (FFT-domain fast convolution, op sequence of mex/nddwt.c) restated with scipy.fft on
     the host cores, complex128 like the mex path -- kind 'port'.  Timed on a bounded sample of the workload.
     Arrays are band-planar with each band contiguous, the reference's column-major layout."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import scipy.fft as sfft
     import ndwt_oracle as orc
@@ -63,30 +103,22 @@ def cpu_baseline(level, wname, sample_sizes, workers):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--size", type=int, nargs=3, default=[512, 512, 512])
-    ap.add_argument("--wname", default="db4")
-    ap.add_argument("--level", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--generic", action="store_true", help="force the per-axis kernels (for comparison)")
-    ap.add_argument("--zchunk", type=int, default=0)
-    ap.add_argument("--target-blocks", type=int, default=0)
-    a = ap.parse_args()
-
-    import torch
-    import importlib
-    pkg = importlib.import_module("non-decimated_wavelets_amd")
-    api = importlib.import_module("non-decimated_wavelets_amd.api")
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    a = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if world == 0:
+        if a.gpus > 1:
+            self_launch(a)                                         # does not return
+        world = 1
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but the launcher started {world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+
+    sys.path.insert(0, ROOT)
+    import importlib
+    import torch
+    api = importlib.import_module("non-decimated_wavelets_amd.api")
+
     # rehearsal of the N > 1 path on a one-GPU box: NDWT_BENCH_BACKEND=gloo (slabs staged through the host) with
     # NDWT_BENCH_ONE_GPU=1 (every rank on device 0).  The driver's runs use neither: one rank per GPU over RCCL.
     backend = os.environ.get("NDWT_BENCH_BACKEND", "nccl")
@@ -104,64 +136,71 @@ def main():
             dist.init_process_group(backend)
     red_dev = dev if backend == "nccl" else torch.device("cpu")     # where the scalar reductions of the report live
 
-    n1, n2, n3 = a.size
-    V = n1 * n2 * n3
-    level = a.level
-    nb = api.num_bands(3, level)
+    d, sizes, level = a.ndim, list(a.size), a.level
+    V = 1
+    for n in sizes:
+        V *= n
+    nbands = api.num_bands(d, level)
     torch.manual_seed(1234 + rank)
+    kshape = tuple(reversed(sizes))                                # kernel order: outermost axis first
 
     force_sharded = os.environ.get("NDWT_BENCH_FORCE_SHARDED", "0") == "1"   # exercise the N>1 code path on one GPU
-    if world == 1 and not force_sharded:
-        plan = api.Plan([n1, n2, n3], [a.wname] * 3, torch.float32, False, True, "reference", max_level=max(level, 3), device=local_rank)
+    sharded = world > 1 or force_sharded
+    if not sharded:
+        plan = api.Plan(sizes, [a.wname] * d, torch.float32, False, True, "reference", max_level=max(level, 3), device=local_rank)
         plan.set_path(a.generic)
         plan.set_tuning(a.target_blocks, a.zchunk)
-        x = torch.randn(n3, n2, n1, device=dev, dtype=torch.float32)
-        y = torch.empty(nb, n3, n2, n1, device=dev, dtype=torch.float32)
+        x = torch.randn(kshape, device=dev, dtype=torch.float32)
+        y = torch.empty((nbands,) + kshape, device=dev, dtype=torch.float32)
         r = torch.empty_like(x)
         stream = torch.cuda.current_stream(dev).cuda_stream
 
         def step():
             plan.dec(x.data_ptr(), y.data_ptr(), level, stream)
             plan.rec(y.data_ptr(), r.data_ptr(), level, stream)
-        kinds = (2, 3) if a.generic else (0, 1)
     else:
         sh = importlib.import_module("non-decimated_wavelets_amd.sharded")
-        eng = sh.ShardedNdDwt([a.wname] * 3, [n1, n2, n3], pres_l2_norm=True, precision="single", group=None, device=dev,
+        eng = sh.ShardedNdDwt([a.wname] * d, sizes, pres_l2_norm=True, precision="single", group=None, device=dev,
                               overlap=os.environ.get("NDWT_BENCH_OVERLAP", "1") == "1")   # 0: exchange and compute in sequence (A/B)
-        x = torch.randn(eng.n_local, n2, n1, device=dev, dtype=torch.float32)
+        x = torch.randn((eng.n_local,) + kshape[1:], device=dev, dtype=torch.float32)
         plan = eng.plan
         r_holder = {}
 
         def step():
             yl = eng.dec(x, level)
             r_holder["r"] = eng.rec(yl)
-        kinds = (0, 1)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
 
     for _ in range(a.warmup):
         step()
-    torch.cuda.synchronize(dev)
-    plan.set_profiling(True)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
+    # ---- timed region: exactly a.steps steps, no per-kernel event recording inside it ----
+    fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
-    torch.cuda.synchronize(dev)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
+    fence()
     dt = time.perf_counter() - t0
     if dist:
         tt = torch.tensor([dt], device=red_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    prof = {k: plan.get_profile(k) for k in kinds}
+
+    # ---- separate pass for the per-kernel figures: HIP events around every launch, on the launch stream ----
+    prof_steps = max(1, min(a.steps, 10))
+    plan.set_profiling(True)
+    for _ in range(prof_steps):
+        step()
+    torch.cuda.synchronize(dev)
+    prof = {k: plan.get_profile(k) for k in KERNEL_NAMES}
     plan.set_profiling(False)
 
-    # round-trip check on the timed data (world == 1)
-    rt_err = None
-    if world > 1 or force_sharded:
+    # round-trip check on the timed data
+    if sharded:
         num = torch.linalg.vector_norm((r_holder["r"] - x).double()) ** 2
         den = torch.linalg.vector_norm(x.double()) ** 2
         if dist:
@@ -169,58 +208,74 @@ def main():
             dist.all_reduce(num)
             dist.all_reduce(den)
         rt_err = float(torch.sqrt(num / den))
-    elif world == 1:
+    else:
         rt_err = float(torch.linalg.vector_norm((r - x).double()) / torch.linalg.vector_norm(x.double()))
 
+    esize = 4
     ms_per_step = dt / a.steps * 1e3
     value = V / (dt / a.steps) / 1e6
-    esize = 4
     v_local = V // world
-    bytes_per_launch = (1 + 8) * v_local * esize                 # one level, one direction (36 B/voxel fp32)
-    # dominant kernel = the kind with the larger total time
-    dom = max(kinds, key=lambda k: prof[k][0])
-    dom_ms, dom_n = prof[dom]
-    # one level of one direction = one launch on a whole volume; the sharded path cuts it into pieces (interior + ends)
-    # that are summed here so that the figure stays "time to move one level's algorithmic bytes"
-    per_level = (world > 1 or force_sharded)
-    avg_ms = dom_ms / max(a.steps * level if per_level else dom_n, 1)
-    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    oth = [k for k in kinds if k != dom][0]
-    names = {0: "fused3_synthesis" if False else "fused3_analysis", 1: "fused3_synthesis", 2: "axis_analysis", 3: "axis_synthesis"}
-    # HBM-side bytes per launch of that kernel from the committed PMC passes (profiles/r01_traffic.json; measured on
-    # this workload, not live) -- null when the run is not the profiled configuration
-    traffic = None
+    step_bytes = 2 * level * (1 + (1 << d)) * V * esize          # whole job, BASELINE.md section 3
+    # dominant kernel = the kind with the largest total time; its algorithmic bytes per launch
+    dom = max(prof, key=lambda k: prof[k][0])
+    per_voxel = {0: 1 + 8, 1: 8 + 1, 2: 1 + 2, 3: 2 + 1}       # volumes read + written per launch: fused 3-D level, one-axis pass
+
+    def kernel_row(k):
+        tot_ms, n = prof[k]
+        if n == 0:
+            return None
+        # one launch covers the rank's whole volume (a 4-D level runs the fused kernel twice, once per t-band, each on all
+        # voxels).  The sharded driver cuts a level into pieces (interior planes + the two ends): their times are summed so
+        # that the figure stays "time to move the algorithmic bytes of v_local voxels".
+        units = prof_steps * level * (2 if (k in (0, 1) and d == 4) else 1) if sharded else n
+        avg_ms = tot_ms / units
+        bytes_launch = per_voxel[k] * v_local * esize
+        ach = bytes_launch / (avg_ms * 1e-3) / 1e9
+        return {"kernel": KERNEL_NAMES[k], "avg_launch_ms": round(avg_ms, 4), "launches": int(n), "algorithmic_bytes": bytes_launch,
+                "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4)}
+
+    rows = {k: kernel_row(k) for k in prof}
+    drow = rows[dom]
+    # HBM-side bytes per launch of the dominant kernel: FETCH_SIZE x 2 + WRITE_SIZE from separate rocprofv3 --pmc passes
+    # of this command (MI355X_MICROARCH.md, HBM section), committed as profiles/r02_traffic.json -- null when this run is
+    # not the profiled configuration
+    traffic, traffic_src = None, None
     try:
-        if world == 1 and [n1, n2, n3] == [512, 512, 512] and a.wname == "db4" and not a.generic:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))[names[dom]]["traffic_bytes"]
+        if not sharded and d == 3 and sizes == [512, 512, 512] and a.wname == "db4" and level == 3 and not a.generic:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+            traffic = tj[drow["kernel"]]["traffic_bytes"]
+            traffic_src = "profiles/r02_traffic.json"
     except Exception:
         traffic = None
-    roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes": bytes_per_launch,
-                "avg_launch_ms": round(avg_ms, 4), "launches": int(dom_n),
-                "other_kernel": {"kernel": names[oth], "avg_launch_ms": round(prof[oth][0] / max(a.steps * level if per_level else prof[oth][1], 1), 4)},
-                "whole_step_frac": round((2 * level * bytes_per_launch * world) / (dt / a.steps) / 1e9 / (HBM_PEAK_GBS * world), 4)}
+    roofline = {"bound": "hbm", "kernel": drow["kernel"], "achieved": drow["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": drow["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes": drow["algorithmic_bytes"], "avg_launch_ms": drow["avg_launch_ms"], "launches": drow["launches"],
+                "other_kernels": [rows[k] for k in rows if k != dom and rows[k] is not None],
+                "whole_step_frac": round(step_bytes / (dt / a.steps) / 1e9 / (HBM_PEAK_GBS * world), 4)}
 
-    out = {"metric": "Mvoxels/s fwd+inv NDWT (512^3 fp32, 3 lvl db4)", "value": round(value, 1), "unit": "Mvoxels/s",
+    shape = "x".join(str(n) for n in sizes)
+    cube = f"{sizes[0]}^3" if d == 3 and len(set(sizes)) == 1 else shape
+    out = {"metric": f"Mvoxels/s fwd+inv NDWT ({cube} fp32, {level} lvl {a.wname})", "value": round(value, 1), "unit": "Mvoxels/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"3D fp32 {n1}x{n2}x{n3} {a.wname} {level} levels, dec+rec, pres_l2_norm, reference dilation (stride 1)",
+           "config": {"workload": f"{d}D fp32 {shape} {a.wname} {level} levels, dec+rec, pres_l2_norm, reference dilation (stride 1)",
                       "sharding": "none" if world == 1 else f"outer-axis slabs x{world}; per level: analysis halo fetch (1 band) and synthesis "
                                                               f"scatter-add (1 band) via RCCL send/recv, overlapped with the interior planes",
-                      "path": "per-axis" if a.generic else "fused3d"},
-           "roofline": roofline}
-    if rt_err is not None:
-        out["roundtrip_rel_l2"] = rt_err
+                      "path": "per-axis" if a.generic else ("fused3d" if d == 3 else "t-axis march + fused3d")},
+           "roofline": roofline, "roundtrip_rel_l2": rt_err}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cores = os.cpu_count() or 1
         workers = min(cores, 16)
-        sample = [512, 512, 128] if cores >= 16 else [192, 192, 128]
+        if d == 3:
+            sample = [512, 512, 128] if cores >= 16 else [192, 192, 128]
+        else:
+            sample = [128, 128, 64, 32] if cores >= 16 else [64, 64, 32, 32]
         v, secs = cpu_baseline(level, a.wname, sample, workers)
         out["cpu_baseline"] = {"value": round(v, 2), "unit": "Mvoxels/s", "cores": workers, "kind": "port",
-                               "sample": f"{sample[0]}x{sample[1]}x{sample[2]} fp64/complex128 {a.wname} {level} levels dec+rec, FFT-domain "
+                               "sample": f"{'x'.join(map(str, sample))} fp64/complex128 {a.wname} {level} levels dec+rec, FFT-domain "
                                          f"restatement of mex/nddwt.c with scipy.fft workers={workers}; {secs:.1f} s"}
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()
 

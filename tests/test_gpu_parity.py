@@ -11,13 +11,13 @@ import numpy as np
 import pytest
 import torch
 
+import helpers
 import ndwt_amd as ndwt
 import ndwt_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
-CLS = {1: ndwt.nd_dwt_1D, 2: ndwt.nd_dwt_2D, 3: ndwt.nd_dwt_3D, 4: ndwt.nd_dwt_4D} if True else {}
 TOL = {"double": 1e-12, "single": 2e-6}
 
 
@@ -116,6 +116,15 @@ RANDOM = [
     (3, [40, 40, 40], ["db8", "db2", "db2"], 2),  # longer than the fused instantiations -> per-axis path
     (4, [12, 9, 10, 11], ["db2", "db1", "db3", "db2"], 2),
     (4, [32, 32, 16, 16], ["db4", "db4", "db4", "db4"], 2),   # example_nd_dwt_4D.m:5 size
+    # the long filters (tap lengths 14, 18, 20) on every axis position, and db5 (10 taps)
+    (1, [333], "db7", 3),
+    (1, [4096], "db10", 2),
+    (2, [68, 40], ["db9", "db7"], 2),
+    (2, [132, 24], ["db5", "db10"], 2),
+    (3, [40, 36, 32], ["db7", "db7", "db7"], 2),
+    (3, [72, 24, 40], ["db9", "db10", "db5"], 2),
+    (3, [64, 40, 44], ["db2", "db3", "db10"], 2),
+    (4, [20, 18, 16, 14], ["db1", "db2", "db1", "db7"], 2),
 ]
 
 
@@ -133,6 +142,45 @@ def test_random_shapes_against_oracle(d, sizes, wname, level, precision, l2):
     c = rng.standard_normal(list(sizes) + [orc.num_bands(d, level)])
     r = w.rec(_colmajor_gpu(c, precision))
     assert _relerr(r.cpu().numpy(), orc.spatial_rec(c, wname, l2)) <= TOL[precision]
+
+
+FUZZ = helpers.fuzz_cases(64, seed=20261004)
+
+
+@pytest.mark.parametrize("case", FUZZ, ids=[helpers.fuzz_id(c) for c in FUZZ])
+def test_fuzz_subset_against_oracle(case):
+    """fixed-seed subset of the randomised sweep of tools/fuzz_gpu.py: dec, rec of arbitrary coefficients, round trip"""
+    d, sizes, wn, level, l2 = case["d"], case["sizes"], case["wn"], case["level"], case["l2"]
+    precision, cplx, dilation = case["precision"], case["cplx"], case["dilation"]
+    rng = np.random.default_rng(case["data_seed"])
+    x = rng.standard_normal(sizes) + (1j * rng.standard_normal(sizes) if cplx else 0)
+    w = _cls(d)(wn if d > 1 else wn[0], sizes, "pres_l2_norm", l2, "precision", precision, "dilation", dilation)
+    xg = _colmajor_gpu(x, precision)
+    y = w.dec(xg, level)
+    want = orc.spatial_dec(x, wn, level, l2, dilation)
+    tol = 3e-6 if precision == "single" else 1e-12             # the sweep's tolerance: worst case seen 0.14 of it
+    assert _relerr(y.cpu().numpy(), want) <= tol
+    assert _relerr(w.rec(y).cpu().numpy(), x) <= 20 * tol
+    c = rng.standard_normal(want.shape) + (1j * rng.standard_normal(want.shape) if cplx else 0)
+    r2 = w.rec(_colmajor_gpu(c, precision))
+    assert _relerr(r2.cpu().numpy(), orc.spatial_rec(c, wn, l2, dilation)) <= 4 * tol
+
+
+@pytest.mark.parametrize("precision", ["double", "single"])
+@pytest.mark.parametrize("l2", [0, 1])
+def test_haar4d_closed_form_of_the_reference(precision, l2):
+    """the db1 known answer the reference ships as signal-domain code (Functions/harr_nddwt_4D.m:262-281,555-579,
+    multi-level bookkeeping :173,:228), against the HIP path: 4-D, 1..3 levels, both pres_l2_norm"""
+    rng = np.random.default_rng(77)
+    sizes = [20, 12, 10, 9]
+    x = rng.standard_normal(sizes)
+    w = ndwt.nd_dwt_4D("db1", sizes, "pres_l2_norm", l2, "precision", precision)
+    for level in (1, 2, 3):
+        want = orc.haar4d_dec(x, level, l2)
+        y = w.dec(_colmajor_gpu(x, precision), level)
+        assert _relerr(y.cpu().numpy(), want) <= TOL[precision]
+        c = rng.standard_normal(want.shape)
+        assert _relerr(w.rec(_colmajor_gpu(c, precision)).cpu().numpy(), orc.haar4d_rec(c, l2)) <= 4 * TOL[precision]
 
 
 def test_fused_and_per_axis_kernels_agree_with_uneven_chunks():

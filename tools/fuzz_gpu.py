@@ -16,30 +16,19 @@ import ndwt_amd as ndwt  # noqa: E402
 import ndwt_oracle as orc  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 max_order = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 p_atrous = float(sys.argv[4]) if len(sys.argv) > 4 else 0.2
 CLS = {1: ndwt.nd_dwt_1D, 2: ndwt.nd_dwt_2D, 3: ndwt.nd_dwt_3D, 4: ndwt.nd_dwt_4D}
 TOL = {"double": 1e-12, "single": 3e-6}
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers  # noqa: E402
+
 worst = 0.0
-for k in range(cases):
-    d = int(rng.choice([1, 2, 3, 3, 3, 4]))
-    budget = {1: 5000, 2: 90, 3: 40, 4: 14}[d]
-    orders = [int(rng.integers(1, min(max_order, 10 if d < 4 else 4) + 1)) for _ in range(d)]
-    sizes = [int(rng.integers(2 * o, max(2 * o + 2, budget))) for o in orders]
-    if rng.random() < 0.3:
-        sizes[0] = int(rng.choice([64, 68, 72, 128, 132])) if d <= 3 else sizes[0]      # whole tiles / ragged tiles
-    level = int(rng.integers(1, 4))
-    dilation = "atrous" if rng.random() < p_atrous else "reference"
-    if dilation == "atrous":                                     # dilated filters (the plan is built for 3 levels) must fit the axis
-        orders = [min(o, 3 if d < 4 else 2) for o in orders]
-        sizes = [max(s, 2 * o * 4) for s, o in zip(sizes, orders)]
-        if rng.random() < 0.7:                                   # axes that divide by 4: the dilated levels run fused on sub-lattices
-            sizes = [4 * ((s + 3) // 4) for s in sizes]
-    l2 = int(rng.integers(0, 2))
-    precision = "single" if rng.random() < 0.5 else "double"
-    cplx = rng.random() < 0.4
-    wn = [f"db{o}" for o in orders]
+for case in helpers.fuzz_cases(cases, seed, max_order, p_atrous):
+    d, sizes, wn, level, l2 = case["d"], case["sizes"], case["wn"], case["level"], case["l2"]
+    precision, cplx, dilation = case["precision"], case["cplx"], case["dilation"]
+    rng = np.random.default_rng(case["data_seed"])
     x = rng.standard_normal(sizes) + (1j * rng.standard_normal(sizes) if cplx else 0)
     w = CLS[d](wn if d > 1 else wn[0], sizes, "pres_l2_norm", l2, "precision", precision, "dilation", dilation)
     xt = torch.from_numpy(np.ascontiguousarray(np.transpose(x))).cuda()
