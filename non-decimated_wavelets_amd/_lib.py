@@ -10,7 +10,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libndwt_hip.so")
+# NDWT_LIB_VARIANT=<name> loads libndwt_hip_<name>.so (diagnostic / tuning builds of tools/, `make VARIANT=<name>`)
+LIB_PATH = os.path.join(_HERE, "libndwt_hip" + ("_" + os.environ["NDWT_LIB_VARIANT"] if os.environ.get("NDWT_LIB_VARIANT") else "") + ".so")
 
 # status codes / enums of include/ndwt.h
 NDWT_OK = 0

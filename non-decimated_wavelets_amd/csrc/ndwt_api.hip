@@ -89,6 +89,7 @@ struct ndwt_plan {
     // optional per-kernel timing with HIP events on the launch stream (bench.py's roofline figures)
     int profiling;
     std::vector<ProfRec>* prof;
+    long long* stamps;                 // diagnostic builds (-DNDWT_STAMPS): device buffer for the per-wave phase cycle sums
 };
 
 static int ensure_tmp(ndwt_plan* p, size_t bytes) {
@@ -351,6 +352,16 @@ void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int
 }
 }  // namespace ndwt
 
+// Float synthesis default: the pair-packed kernel.  It derives the high-pass taps from the low-pass ones (mirror + alternating
+// signs), which holds for the zero-padded taps of an axis when its padding (Lp - len) / 2 is even; it keeps plane offsets in
+// 32-bit BYTE counts.  variant_inv 4 forces the older lane-shift kernel (Inv3S) for A/B runs.
+template <typename T> static bool inv3y_eligible(const ndwt_plan* p, int Lp, const Fused3Args<T>& a) {
+    if (p->dtype != NDWT_F32 || p->comp != 1 || Lp > 8 || p->variant_inv == 3 || p->variant_inv == 4) return false;
+    for (int ax = 0; ax < 3; ++ax)
+        if (((Lp - p->filt[ax].len) / 2) % 2 != 0) return false;
+    return (long long)a.rs * a.n2 < (1LL << 30);
+}
+
 // one fused 3-D launch over `nbatch` volumes. n3 = output planes; z_wrap=false: inputs carry the z halo
 template <typename T>
 static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* in, T* const* out, long long n3, long long nbatch,
@@ -372,7 +383,7 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     a.in_bstride = in_bstride;
     a.out_bstride = out_bstride;
     a.z_wrap = z_mode;
-    if (const char* v = getenv("NDWT_DEBUG")) a.dbg = atoi(v);   // timing experiments only
+    a.stamps = p->stamps;
     bool vec4 = (a.n1 % 4 == 0) && (in_bstride % 4 == 0) && (out_bstride % 4 == 0);
     const int nin = inverse ? 8 : (z_mode == 2 ? 3 : 1), nout = inverse ? 1 : 8;
     for (int b = 0; b < nin; ++b) { a.in[b] = in[b]; vec4 = vec4 && aligned_vec4<T>(in[b]); }
@@ -401,7 +412,11 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     const void* td = p->taps_dev[inverse ? 1 : 0];
     if (!td) return fail(NDWT_ERR_UNSUPPORTED, "plan has no device tap table");
     prof_begin(p, inverse ? NDWT_KERNEL_FUSED_SYNTHESIS : NDWT_KERNEL_FUSED_ANALYSIS, s);
-    int rc = launch3<T>(inverse, a, t, vec4, variant, dil > 1 ? dil : (int)p->comp, td, s);
+    int rc = -1;
+    if constexpr (sizeof(T) == 4) {
+        if (inverse && dil == 1 && inv3y_eligible(p, Lp, a)) rc = launch_inv3y_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s);
+    }
+    if (rc == -1) rc = launch3<T>(inverse, a, t, vec4, variant, dil > 1 ? dil : (int)p->comp, td, s);
     prof_end(p, s);
     if (rc == -1) return fail(NDWT_ERR_UNSUPPORTED, "no fused kernel instantiated for tap length %d", Lp);
     if (rc != 0) return fail(NDWT_ERR_HIP, "fused kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -851,7 +866,8 @@ int ndwt_plan_create(ndwt_plan** plan, int ndim, const int64_t* dims, const char
     if (fused3_eligible(p, 1, &Lp) || fused2_eligible(p, 1, &Lp)) {
         for (int inv = 0; inv < 2; ++inv) {
             FusedTapsD t = fused_taps(p, Lp, inv != 0);
-            std::vector<char> host((size_t)6 * Lp * p->esize);
+            // synthesis table: Taps3Y = Taps3 followed by the x tap pairs (lo[0][k], lo[0][k-1]), k = 0..Lp, of the pair-packed kernel
+            std::vector<char> host((size_t)(6 * Lp + (inv ? 4 * (Lp + 1) : 0)) * p->esize);
             for (int ax = 0; ax < 3; ++ax)
                 for (int j = 0; j < Lp; ++j) {
                     if (dtype == NDWT_F32) {
@@ -862,6 +878,16 @@ int ndwt_plan_create(ndwt_plan** plan, int ndim, const int64_t* dims, const char
                         ((double*)host.data())[3 * Lp + ax * Lp + j] = t.hi[ax][j];
                     }
                 }
+            if (inv) {
+                for (int k = 0; k <= Lp; ++k)
+                    for (int h = 0; h < 2; ++h) {
+                        const int j = k - h;                                  // (t[k], t[k-1])
+                        const double vlo = (j >= 0 && j < Lp) ? t.lo[0][j] : 0.0, vhi = (j >= 0 && j < Lp) ? t.hi[0][j] : 0.0;
+                        const size_t ilo = (size_t)6 * Lp + 2 * k + h, ihi = ilo + 2 * (Lp + 1);
+                        if (dtype == NDWT_F32) { ((float*)host.data())[ilo] = (float)vlo; ((float*)host.data())[ihi] = (float)vhi; }
+                        else { ((double*)host.data())[ilo] = vlo; ((double*)host.data())[ihi] = vhi; }
+                    }
+            }
             hipError_t e = hipMalloc(&p->taps_dev[inv], host.size());
             if (e == hipSuccess) e = hipMemcpy(p->taps_dev[inv], host.data(), host.size(), hipMemcpyHostToDevice);
             if (e != hipSuccess) {
@@ -1215,6 +1241,15 @@ int ndwt_analysis_level_slab_runs(ndwt_plan* p, const void* in_with_halo, void* 
                ? slab_analysis_runs_impl<float>(p, Lp, in_with_halo, out, n_planes, n_runs, run_stride, (hipStream_t)stream)
                : slab_analysis_runs_impl<double>(p, Lp, in_with_halo, out, n_planes, n_runs, run_stride, (hipStream_t)stream);
 }
+
+#ifdef NDWT_STAMPS
+// diagnostic builds only (tools/stamps_inv.py): 4 cycle sums per wave of every workgroup of the next synthesis launches
+int ndwt_plan_set_stamps(ndwt_plan* p, void* dev_buffer) {
+    if (!p) return fail(NDWT_ERR_INVALID_ARG, "null plan");
+    p->stamps = (long long*)dev_buffer;
+    return NDWT_OK;
+}
+#endif
 
 const char* ndwt_last_error(void) { return g_last_error.c_str(); }
 const char* ndwt_version(void) { return "ndwt-hip 0.1 (gfx950)"; }

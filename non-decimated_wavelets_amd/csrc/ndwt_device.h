@@ -177,7 +177,7 @@ template <typename T> struct Fused3Args {
     // hard with shrink_hard) -- the thresholding of the detail bands fused into the reconstruction
     T shrink_thr;
     int shrink_mask, shrink_hard;
-    int dbg;               // timing experiments only (wrong results): bit0 = fold halo reads back into the tile
+    long long* stamps;     // diagnostic builds (-DNDWT_STAMPS) only: per wave, cycles spent in each phase of the plane loop
 };
 
 // XCD-aware block order: hardware deals workgroups round-robin over the 8 XCDs (each with its own
@@ -326,7 +326,6 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
             int ug = c % NG, r = c / NG;
             int y = modn(tc.y0 - LH + r, a.n2);
             int xb = tc.x0 - 4 * GL + 4 * ug;
-            if (a.dbg & 1) { y = modn(tc.y0 + r % TY, a.n2); xb = tc.x0 + 4 * (ug % (TX / 4)); }
             NDWT_SFOR(e, NE)
                 st.off[k][e] = y * a.rs + modn(xb + e, a.n1);
             NDWT_SEND
@@ -541,7 +540,6 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
             int ug = it % NG, r = (it / NG) % NR;
             int y = modn(tc.y0 - LH + r, a.n2);
             int xb = tc.x0 - 4 * GL + 4 * ug;
-            if (a.dbg & 1) { y = modn(tc.y0 + r % TY, a.n2); xb = tc.x0 + 4 * (ug % (TX / 4)); }
             NDWT_SFOR(e, NE)
                 st.off[k][e] = y * a.rs + modn(xb + e, a.n1);
             NDWT_SEND
@@ -711,6 +709,14 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
     }
 };
 
+#ifdef NDWT_HOST_EMU
+#define NDWT_SCHED_FENCE() ((void)0)
+#define NDWT_SETPRIO(n) ((void)(n))
+#else
+#define NDWT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)   // the instruction scheduler moves nothing across this point
+#define NDWT_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#endif
+
 // ------------------------------------------------------------------- synthesis, lane-shift form ----
 // Same arithmetic as Inv3 with a different data path: the x-synthesis takes its x neighbours straight from the
 // adjacent lanes' registers (DPP wave shifts) instead of a raw tile in LDS.  A wave holds whole haloed rows
@@ -802,9 +808,11 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
             lane_item(tid, k, ug, r, valid);
             int y = modn(tc.y0 - LH + r, a.n2);
             int xb = tc.x0 - 4 * GL + 4 * ug;
-            if (a.dbg & 1) { y = modn(tc.y0 + r % TY, a.n2); xb = tc.x0 + 4 * (ug % (TX / 4)); }
             NDWT_SFOR(e, NE)
-                st.off[k][e] = y * a.rs + modn(xb + e, a.n1);
+                st.off[k][e] = valid ? y * a.rs + modn(xb + e, a.n1) : -1;   // -1: this lane holds no row and loads nothing
+            NDWT_SEND
+            NDWT_SFOR(b, 8)
+                st.raw[k][b] = (v4)(T(0));               // lanes without a row keep zeros (their values reach no output)
             NDWT_SEND
         NDWT_SEND
     }
@@ -824,16 +832,20 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
         }
         long long pb = ibase + zm * a.plane;
         NDWT_SFOR(k, NRND)
-            NDWT_SFOR(b, 8)
-                const T* p = a.in[b] + pb;
-                if constexpr (VEC4) {
-                    st.raw[k][b] = *reinterpret_cast<const v4*>(p + st.off[k][0]);
-                } else {
-                    NDWT_SFOR(e, NE)
-                        st.raw[k][b][e] = p[st.off[k][e]];
-                    NDWT_SEND
-                }
-            NDWT_SEND
+            // lanes (and whole waves) without a row issue no loads: the per-CU vector-memory pipe bounds these kernels, and the
+            // waves past the last haloed row used to re-load a clamped row (3 of 16 waves on the 64x32 tile)
+            if (st.off[k][0] >= 0) {
+                NDWT_SFOR(b, 8)
+                    const T* p = a.in[b] + pb;
+                    if constexpr (VEC4) {
+                        st.raw[k][b] = *reinterpret_cast<const v4*>(p + st.off[k][0]);
+                    } else {
+                        NDWT_SFOR(e, NE)
+                            st.raw[k][b][e] = p[st.off[k][e]];
+                        NDWT_SEND
+                    }
+                NDWT_SEND
+            }
         NDWT_SEND
     }
 
@@ -973,17 +985,484 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
             setup(st, a, tc, tid);
             load_raw(st, a, ibase, tc.zbeg - LH, zsh);
         });
+#if defined(NDWT_STAMPS) && !defined(NDWT_HOST_EMU)
+        unsigned long long acc_wait = 0, acc_x = 0, acc_bar = 0, acc_yz = 0, t0;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
+#define NDWT_STAMP(accu) { unsigned long long t1_; __builtin_amdgcn_sched_barrier(0); \
+                           asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_) :: "memory"); \
+                           __builtin_amdgcn_sched_barrier(0); accu += t1_ - t0; t0 = t1_; }
+#else
+#define NDWT_STAMP(accu)
+#endif
         for (int p = 0; p < nplanes; ++p) {
             const int s = p - (L - 1);
+#if defined(NDWT_STAMPS) && !defined(NDWT_HOST_EMU)
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the wait for this plane's loads, timed on its own
+            NDWT_STAMP(acc_wait)
+#endif
             ex.each([&](int, State& st) __attribute__((always_inline)) { shrink_raw(st, a); });
             ex.each([&](int tid, State& st) __attribute__((always_inline)) { xsyn(ex, st, sh, tp, p & 1, tid); });
+            NDWT_STAMP(acc_x)
             ex.each([&](int, State& st) __attribute__((always_inline)) {                 // (separate pass only matters to the host emulator)
                 if (p + 1 < nplanes) load_raw(st, a, ibase, tc.zbeg - LH + p + 1, zsh);
             });
             ex.barrier();
+            NDWT_STAMP(acc_bar)
+            NDWT_SETPRIO(1);                              // the short y / z stage and its store ahead of every wave's x stage and loads
             ex.each([&](int tid, State& st) __attribute__((always_inline)) {
                 yzdispatch<0>((p + 1) % L, st, sh, tp, a, tc, obase, tc.zbeg + s, s >= 0, p & 1, tid);
             });
+            NDWT_SETPRIO(0);
+            NDWT_STAMP(acc_yz)
+        }
+#if defined(NDWT_STAMPS) && !defined(NDWT_HOST_EMU)
+        if (a.stamps && threadIdx.x % 64 == 0) {
+            long long* d = a.stamps + ((long long)bid * (NT / 64) + threadIdx.x / 64) * 4;
+            d[0] = (long long)acc_wait; d[1] = (long long)acc_x; d[2] = (long long)acc_bar; d[3] = (long long)acc_yz;
+        }
+#endif
+    }
+};
+
+// ---------------------------------------------------------- synthesis, pair-packed lane-shift form ----
+// The float default (real data, stride 1, tap lengths <= 8).  Same data path as Inv3S -- x neighbours by DPP wave shifts, the
+// x-synthesised tile through LDS with one barrier per plane, z in scatter form -- rebuilt around what the round-2
+// measurements showed (tools/timeline_inv.py, tools/micro/valu_rate.hip):
+//  * The kernel is bound by the per-CU VECTOR-MEMORY PIPE (about 70 cycles per 1-KiB load instruction), not by arithmetic:
+//    lanes and waves that hold no row issue no loads (Inv3S let them re-load a clamped row: 24 of 128 load instructions per
+//    plane), and band pointers are wave-uniform SGPR bases + a 32-bit lane offset instead of eight 64-bit VGPR pairs.
+//  * Waves stall on their own loads until the pipe accepts them, so WHEN loads are issued matters more than how far ahead:
+//    with two register sets (DEPTH 2) half of the waves refill at the start of a plane and half after their x stage, and
+//    loads are being issued through the whole plane.  The y / z stages run at raised priority (s_setprio): under oldest-first
+//    arbitration the youngest waves' store waited behind the older waves' queued loads and the workgroup waited for them.
+//  * All arithmetic is on PAIRS OF ADJACENT x (v_pk_fma_f32: 4.3 cycles per wave-instruction for two FMAs per lane, against
+//    4.2 for one v_fmac_f32 with a scalar tap).  x stage: outputs (e, e+1) of one lane share the window element w and take
+//    the adjacent taps (t[k], t[k-1]), a pair the host stores in the tap table (Taps3Y::xplo).  An LDS chunk holds, for
+//    two adjacent x, (z-bit 0: x0, x1 | z-bit 1: x0, x1), so the y and z stages run on (x0, x1) pairs as well.
+//  * Only the low-pass taps live in SGPRs (34 of them): the high-pass taps are the low-pass taps mirrored with alternating
+//    signs, applied by the op_sel / neg modifiers of the packed FMA (the host checks the padding parity this relies on).
+template <typename T, int L> struct Taps3Y {             // the first two members are Taps3<T, L>: one table serves every kernel
+    T lo[3][L];
+    T hi[3][L];
+    T xplo[L + 1][2];        // (lo[0][k], lo[0][k-1]), k = 0..L, taps outside [0, L) = 0
+    T xphi[L + 1][2];        // the same for the high-pass taps (not read by Inv3Y, which derives them)
+};
+
+template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 4, int DEPTH_ = 1> struct Inv3Y {
+    static_assert(sizeof(T) == 4, "pair-packed synthesis: float only (v_pk_fma_f32)");
+    static constexpr int L = L_, TX = TX_, TY = TY_, NT = NT_, WPE = WPE_, EW = 1;
+    static constexpr bool VEC4 = VEC4_;
+    static constexpr int DEPTH = DEPTH_;                 // register sets of band loads per lane (planes in flight)
+    static_assert(DEPTH == 1 || DEPTH == 2, "one or two register sets");
+    static constexpr int NE = VEC4 ? 1 : 4;
+    static constexpr int LH = L / 2, RH = L / 2 - 1;
+    static constexpr int GL = (LH + 3) / 4, GR = (RH + 3) / 4;
+    static constexpr int NG = TX / 4 + GL + GR;          // lanes per haloed row
+    static constexpr int NR = TY + L - 1;                // haloed rows: loaded, x-synthesised, kept in LDS
+    static constexpr int RPW = 64 / NG;                  // rows per wave
+    static constexpr int NW = NT / 64;
+    static constexpr int RPR = RPW * NW;                 // rows per round
+    static constexpr int NRND = (NR + RPR - 1) / RPR;
+    static constexpr int TXC = TX / 2;                   // chunks per row: one 16-byte chunk = two adjacent x
+    static constexpr int YITEMS = TXC * TY;              // y/z item: one chunk column of one output row
+    static constexpr int NYI = (YITEMS + NT - 1) / NT;
+    static constexpr int XV = 4 * (1 + GL + GR);
+    static constexpr int KB = LH - 4 * GL;               // window element i feeds output e through tap j = i + KB - e
+    static constexpr int YG = DEPTH == 2 ? 4 : 8;        // LDS chunks the y stage holds at a time
+    static constexpr unsigned kNoRow = 0xFFFFFFFFu;      // State::off of a lane that holds no row
+    static_assert(TX % 4 == 0 && L % 2 == 0 && NT % 64 == 0 && RPW >= 1, "tile shape");
+    typedef typename VecT<T>::v2 v2;
+    typedef typename VecT<T>::v4 v4;
+    typedef Lds<T> LD;
+    typedef v4 chunk;
+    typedef Taps3Y<T, L> Taps;
+    typedef Fused3Args<T> Args;
+
+    struct Shared {
+        chunk xs[2][2][NR][TXC];   // [buffer][y-bit][row][x pair] of (z-bit 0: x0, x1 | z-bit 1: x0, x1)
+    };
+    struct State {
+        v2 zacc[NYI][L];           // z-synthesis in scatter form: partial sums of the next L output planes (x0, x1), rotating
+        v4 raw[DEPTH][NRND][8];    // 4 x of every band of this lane's row(s); DEPTH 2: the set index is the plane's parity
+        unsigned off[NRND][NE];    // BYTE offsets inside a plane (kNoRow: this lane holds no row and loads nothing)
+        v2 P[NYI][2];              // y-synthesised (x0, x1) pairs of the newest plane: z-low / z-high inputs of the z stage
+        unsigned ooff[NYI];        // byte offset of this thread's output pair inside a plane
+        int ostore[NYI];           // outputs this thread stores: 0 none (outside the volume), 1 the first x only, 2 the pair
+    };
+
+    // the taps the kernel uses, read once per workgroup into SGPR pairs (low-pass only: the high-pass ones are derived by the
+    // operand modifiers of the packed FMAs).  Passed through an empty asm so that the compiler treats them as values to keep
+    // in registers: as loads from constant memory it re-issues them (s_load + lgkmcnt(0)) inside every band of the x stage.
+    struct RegTaps {
+        v2 xp[L + 1];              // (lo_x[k], lo_x[k-1])
+        v2 yl[L / 2], zl[L / 2];   // (lo[2m], lo[2m+1]) of the y and z axes
+    };
+    static NDWT_DEV v2 pinned(v2 t) {
+#ifndef NDWT_HOST_EMU
+        asm volatile("" : "+s"(t));
+#endif
+        return t;
+    }
+    static NDWT_DEV void load_taps(RegTaps& rt, const Taps& tp) {
+        NDWT_SFOR(k, L + 1)
+            rt.xp[k] = pinned(v2{tp.xplo[k][0], tp.xplo[k][1]});
+        NDWT_SEND
+        NDWT_SFOR(m, L / 2)
+            rt.yl[m] = pinned(v2{tp.lo[1][2 * m], tp.lo[1][2 * m + 1]});
+            rt.zl[m] = pinned(v2{tp.lo[2][2 * m], tp.lo[2][2 * m + 1]});
+        NDWT_SEND
+    }
+
+    // Global memory through a WAVE-UNIFORM base (kernel arguments and tile coordinates only) plus a 32-bit per-lane byte
+    // offset: the scalar-base addressing form.  readfirstlane pins the base to SGPRs -- without it hipcc hoists
+    // `band pointer + lane offset` out of the plane loop as eight 64-bit VGPR pairs -- and the address_space(1) casts keep the
+    // accesses global_* (a pointer rebuilt from integers would otherwise be a flat one).
+#ifndef NDWT_HOST_EMU
+    typedef const __attribute__((address_space(1))) char* gcptr;
+    typedef __attribute__((address_space(1))) char* gptr;
+    static NDWT_DEV unsigned long long uniform_bits(const void* p) {
+        const unsigned long long v = (unsigned long long)p;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return ((unsigned long long)hi << 32) | lo;
+    }
+    template <class V> static NDWT_DEV V gload(const void* base, unsigned off) {
+        return *reinterpret_cast<const __attribute__((address_space(1))) V*>((gcptr)uniform_bits(base) + off);
+    }
+    template <class V> static NDWT_DEV void gstore(void* base, unsigned off, V v) {
+        *reinterpret_cast<__attribute__((address_space(1))) V*>((gptr)uniform_bits(base) + off) = v;
+    }
+#else
+    template <class V> static NDWT_DEV V gload(const void* base, unsigned off) { return *reinterpret_cast<const V*>((const char*)base + off); }
+    template <class V> static NDWT_DEV void gstore(void* base, unsigned off, V v) { *reinterpret_cast<V*>((char*)base + off) = v; }
+#endif
+
+    // ---- packed FMAs with explicit operand selection (v_pk_fma_f32 op_sel / neg modifiers) ----
+    // Why by hand: (1) hipcc keeps a scalar multiplier of a packed FMA as a DUPLICATED SGPR pair (t, t); (2) the high-pass
+    // taps are the low-pass taps mirrored with alternating signs (s_hi[j] = (-1)^(j+1) s_lo[L-1-j], ndwt_filters.h; the
+    // symmetric zero padding to L keeps this when the padding on each side is even), which the hardware applies for free
+    // through op_sel (swap the halves of a tap pair) and neg_lo / neg_hi.  Together: 34 SGPRs of taps instead of 132, so the
+    // tap table stays in SGPRs across the plane loop instead of being reloaded (s_load + lgkmcnt(0)) or spilled to VGPR
+    // lanes (v_readlane) inside it.  The statements are not volatile: the compiler still schedules them.
+    // acc += (a[SELA], a[SELA]) * (t0, t1) with (t0, t1) = tp, or (tp[1], tp[0]) if SWAP; NEGLO / NEGHI negate t0 / t1.
+    template <int SELA, bool SWAP, bool NEGLO, bool NEGHI> static NDWT_DEV void pk_fma_bt(v2& acc, const v2 a, const v2 tp) {
+#ifndef NDWT_HOST_EMU
+#define NDWT_PKF(A, S, NS, NL, NH)                                                                                                  \
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[" #A "," #S ",0] op_sel_hi:[" #A "," #NS ",1] neg_lo:[0," #NL ",0] neg_hi:[0," #NH ",0]" \
+            : "+v"(acc) : "v"(a), "s"(tp))
+        if constexpr (SELA == 0 && !SWAP) NDWT_PKF(0, 0, 1, 0, 0);
+        else if constexpr (SELA == 1 && !SWAP) NDWT_PKF(1, 0, 1, 0, 0);
+        else if constexpr (SELA == 0 && NEGLO) NDWT_PKF(0, 1, 0, 1, 0);
+        else if constexpr (SELA == 1 && NEGLO) NDWT_PKF(1, 1, 0, 1, 0);
+        else if constexpr (SELA == 0) NDWT_PKF(0, 1, 0, 0, 1);
+        else NDWT_PKF(1, 1, 0, 0, 1);
+#undef NDWT_PKF
+        static_assert(SWAP ? (NEGLO != NEGHI) : (!NEGLO && !NEGHI), "forms used by the x stage");
+#else
+        acc.x += a[SELA] * (NEGLO ? -tp[SWAP ? 1 : 0] : tp[SWAP ? 1 : 0]);
+        acc.y += a[SELA] * (NEGHI ? -tp[SWAP ? 0 : 1] : tp[SWAP ? 0 : 1]);
+#endif
+    }
+    // acc += x * (t, t), t = tp[HI], negated if NEG
+    template <int HI, bool NEG> static NDWT_DEV void pk_fma_s(v2& acc, const v2 x, const v2 tp) {
+#ifndef NDWT_HOST_EMU
+        if constexpr (HI == 0 && !NEG) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(x), "s"(tp));
+        else if constexpr (HI == 1 && !NEG) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "s"(tp));
+        else if constexpr (HI == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "+v"(acc) : "v"(x), "s"(tp));
+        else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "+v"(acc) : "v"(x), "s"(tp));
+#else
+        acc += x * (NEG ? -tp[HI] : tp[HI]);
+#endif
+    }
+    // acc += x * low-pass tap J (HIGH = false) or high-pass tap J = (-1)^(J+1) low-pass tap L-1-J, from the low-pass tap pairs `lo`
+    template <int J, bool HIGH> static NDWT_DEV void tap_fma(v2& acc, const v2 x, const v2 (&lo)[L / 2]) {
+        constexpr int jj = HIGH ? L - 1 - J : J;
+        pk_fma_s<jj & 1, HIGH && (J % 2 == 0)>(acc, x, lo[jj / 2]);
+    }
+    // acc(e, e+1) += (t[K], t[K-1]) * w[H]: the x taps of two adjacent outputs for one window entry.  Low-pass: the pair
+    // xp[K].  High-pass: (hi[K], hi[K-1]) = ((-1)^(K+1) lo[L-1-K], (-1)^K lo[L-K]) = the halves of xp[L-K] swapped, one negated.
+    template <int H, int K, bool HIGH> static NDWT_DEV void xtap(v2& acc, const v2 w, const RegTaps& tp) {
+        if constexpr (!HIGH) pk_fma_bt<H, false, false, false>(acc, w, tp.xp[K]);
+        else pk_fma_bt<H, true, K % 2 == 0, K % 2 != 0>(acc, w, tp.xp[L - K]);
+    }
+
+    static NDWT_DEV void lane_item(int tid, int rnd, int& ug, int& r, bool& valid) {
+        const int lane = tid % 64, wv = tid / 64;
+        const int rs = lane / NG;
+        ug = lane % NG;
+        r = rnd * RPR + wv * RPW + rs;
+        valid = rs < RPW && r < NR;
+        if (r >= NR) r = NR - 1;
+    }
+    // DEPTH 2: the waves that refill a register set at the START of a plane rather than after their x stage.  Waves w, w+4,
+    // w+8, w+12 share a SIMD: every SIMD gets two of each kind.
+    static NDWT_DEV bool early_refill(int tid) { return (((tid >> 6) >> 2) & 1) == 1; }
+
+    static NDWT_DEV void setup(State& st, const Args& a, const TileCoord& tc, int tid) {
+        NDWT_SFOR(k, NRND)
+            int ug, r;
+            bool valid;
+            lane_item(tid, k, ug, r, valid);
+            const int y = modn(tc.y0 - LH + r, a.n2);
+            const int xb = tc.x0 - 4 * GL + 4 * ug;
+            NDWT_SFOR(e, NE)
+                st.off[k][e] = valid ? (unsigned)(y * a.rs + modn(xb + e, a.n1)) * (unsigned)sizeof(T) : kNoRow;
+            NDWT_SEND
+        NDWT_SEND
+        NDWT_SFOR(d, DEPTH)                               // lanes without a row keep zeros (their values reach no output)
+            NDWT_SFOR(k, NRND)
+                NDWT_SFOR(b, 8)
+                    st.raw[d][k][b] = (v4)(T(0));
+                NDWT_SEND
+            NDWT_SEND
+        NDWT_SEND
+        NDWT_SFOR(k, NYI)                                 // where this thread's output pair goes
+            const int it = tid + k * NT;
+            const int cx = it % TXC, q = it / TXC;
+            const int gx = tc.x0 + 2 * cx, gy = tc.y0 + q;
+            st.ostore[k] = (it < YITEMS && gy < a.n2 && gx < a.n1) ? (gx + 1 < a.n1 ? 2 : 1) : 0;
+            st.ooff[k] = st.ostore[k] ? (unsigned)(gy * a.rs + gx) * (unsigned)sizeof(T) : 0u;
+        NDWT_SEND
+    }
+
+    // issue the loads of plane zraw into register set SET (lanes, and whole waves, without a row issue none)
+    template <int SET> static NDWT_DEV void load_raw(State& st, const Args& a, long long ibase, int zraw, int zsh) {
+        long long zm = a.z_wrap == 1 ? (long long)modn(zraw, a.n3) : (long long)(zraw + LH);
+        if (a.z_wrap == 3) {                             // zero-extended slab
+            zm = zraw - RH;
+            if (zm + zsh < a.zlo || zm + zsh >= a.zhi) {
+                NDWT_SFOR(k, NRND)
+                    NDWT_SFOR(b, 8)
+                        st.raw[SET][k][b] = (v4)(T(0));
+                    NDWT_SEND
+                NDWT_SEND
+                return;
+            }
+        }
+        const long long pb = ibase + zm * a.plane;
+        NDWT_SFOR(k, NRND)
+            if (st.off[k][0] != kNoRow) {
+                NDWT_SFOR(b, 8)
+                    const T* p = a.in[b] + pb;           // wave-uniform
+                    if constexpr (VEC4) {
+                        st.raw[SET][k][b] = gload<v4>(p, st.off[k][0]);
+                    } else {
+                        NDWT_SFOR(e, NE)
+                            st.raw[SET][k][b][e] = gload<T>(p, st.off[k][e]);
+                        NDWT_SEND
+                    }
+                NDWT_SEND
+            }
+        NDWT_SEND
+    }
+
+    template <int SET> static NDWT_DEV void shrink_raw(State& st, const Args& a) {
+        if (a.shrink_mask == 0) return;
+        NDWT_SFOR(k, NRND)
+            NDWT_SFOR(b, 8)
+                if ((a.shrink_mask >> b) & 1) shrink4<T, 1>(st.raw[SET][k][b], a.shrink_thr, a.shrink_hard);
+            NDWT_SEND
+        NDWT_SEND
+    }
+
+    // x-synthesis of this lane's 4 x, as the two pairs (0,1) and (2,3): pair01 = sum_i (t[k], t[k-1]) w_i with k = i + KB,
+    // pair23 the same with k = i + KB - 2
+    template <int SET, class Exec>
+    static NDWT_DEV void xsyn(Exec& ex, State& st, Shared& sh, const RegTaps& tp, int buf, int tid) {
+        NDWT_SFOR(k, NRND)
+            int ug, r;
+            bool valid;
+            lane_item(tid, k, ug, r, valid);
+            NDWT_SFOR(yb, 2)
+                v2 acc[2][2];                            // [z-bit][pair 01 / 23]
+                NDWT_SFOR(zb, 2)
+                    acc[zb][0] = (v2)(T(0));
+                    acc[zb][1] = (v2)(T(0));
+                    // one input band at a time (x-low then x-high of this z-bit).  The window is held as PAIRS of adjacent
+                    // entries -- the halves of the loaded v4 of this lane, and of the neighbours' shifted into this lane --
+                    // so that every packed-FMA operand is an aligned register pair with nothing wasted.
+                    NDWT_SFOR(xb, 2)
+                        NDWT_SFOR(m, XV / 2)
+                            constexpr int D = (2 * m) / 4 - GL;      // lane distance of window entries 2m, 2m+1
+                            constexpr int c = (2 * m) % 4;
+                            constexpr int ka = 2 * m + KB, kb = 2 * m + 1 + KB;        // tap-pair index of entry 2m / 2m+1 for outputs (0,1)
+                            constexpr bool ua01 = ka >= 0 && ka <= L, ub01 = kb >= 0 && kb <= L;
+                            constexpr bool ua23 = ka - 2 >= 0 && ka - 2 <= L, ub23 = kb - 2 >= 0 && kb - 2 <= L;
+                            if constexpr (ua01 || ub01 || ua23 || ub23) {
+                                const v2 w = {NDWT_LANE_SHIFT(ex, tid, D, s.raw[SET][k][xb + 2 * yb + 4 * zb][c]),
+                                              NDWT_LANE_SHIFT(ex, tid, D, s.raw[SET][k][xb + 2 * yb + 4 * zb][c + 1])};
+                                if constexpr (ua01) xtap<0, ka, xb == 1>(acc[zb][0], w, tp);
+                                if constexpr (ub01) xtap<1, kb, xb == 1>(acc[zb][0], w, tp);
+                                if constexpr (ua23) xtap<0, ka - 2, xb == 1>(acc[zb][1], w, tp);
+                                if constexpr (ub23) xtap<1, kb - 2, xb == 1>(acc[zb][1], w, tp);
+                            }
+                        NDWT_SEND
+                        NDWT_SCHED_FENCE();               // hipcc otherwise hoists every DPP move of a y-bit ahead of the FMAs
+                    NDWT_SEND
+                NDWT_SEND
+                if (valid && ug >= GL && ug < GL + TX / 4) {
+                    const chunk c0 = {acc[0][0].x, acc[0][0].y, acc[1][0].x, acc[1][0].y};
+                    const chunk c1 = {acc[0][1].x, acc[0][1].y, acc[1][1].x, acc[1][1].y};
+                    chunk* row = sh.xs[buf][yb][r];
+                    row[LD::S(2 * (ug - GL))] = c0;
+                    row[LD::S(2 * (ug - GL) + 1)] = c1;
+                }
+            NDWT_SEND
+        NDWT_SEND
+    }
+
+    // y-synthesis of output row q from LDS rows q .. q+L-1: the (x0, x1) pairs of the z-low / z-high inputs of the z-synthesis.
+    // Kept apart from the z stage so that it exists once, not once per rotation of the z window.
+    static NDWT_DEV void ysyn(State& st, Shared& sh, const RegTaps& tp, int buf, int tid) {
+        NDWT_SFOR(k, NYI)
+            const int it = tid + k * NT;
+            v2 P0 = (v2)(T(0)), P1 = (v2)(T(0));
+            if (it < YITEMS) {
+                const int cx = it % TXC, q = it / TXC;
+                const int pc = LD::S(cx);
+                NDWT_SFOR(yb, 2)
+                    NDWT_SFOR(h, (L + YG - 1) / YG)            // YG chunks at a time: the register footprint of the LDS reads
+                        chunk cv[YG];
+                        NDWT_SFOR(t, YG)
+                            if constexpr (h * YG + t < L) cv[t] = sh.xs[buf][yb][q + h * YG + t][pc];
+                        NDWT_SEND
+                        NDWT_SFOR(t, YG)
+                            if constexpr (h * YG + t < L) {
+                                tap_fma<h * YG + t, yb == 1>(P0, v2{cv[t][0], cv[t][1]}, tp.yl);
+                                tap_fma<h * YG + t, yb == 1>(P1, v2{cv[t][2], cv[t][3]}, tp.yl);
+                            }
+                        NDWT_SEND
+                        NDWT_SCHED_FENCE();               // the next group's chunks are read after this one's are consumed
+                    NDWT_SEND
+                NDWT_SEND
+            }
+            st.P[k][0] = P0;
+            st.P[k][1] = P1;
+        NDWT_SEND
+    }
+
+    // z-synthesis in scatter form (rotation R as in Inv3S) and the store of the plane it completes
+    template <int R>
+    static NDWT_DEV void zsyn(State& st, const RegTaps& tp, const Args& a, long long obase, int z, bool emit, int tid) {
+        NDWT_SFOR(k, NYI)
+            const int it = tid + k * NT;
+            if (it < YITEMS) {
+                const v2 P0 = st.P[k][0], P1 = st.P[k][1];
+                NDWT_SFOR(j, L)
+                    constexpr int slot = ((R - 1 - j) % L + L) % L;
+                    if constexpr (j == 0) st.zacc[k][slot] = (v2)(T(0));
+                    tap_fma<j, false>(st.zacc[k][slot], P0, tp.zl);
+                    tap_fma<j, true>(st.zacc[k][slot], P1, tp.zl);
+                NDWT_SEND
+                if (emit && st.ostore[k]) {
+                    constexpr int done = ((R - L) % L + L) % L;
+                    const v2 o = st.zacc[k][done];
+                    T* dst = a.out[0] + obase + (long long)z * a.plane;   // wave-uniform
+                    if constexpr (VEC4) {
+                        gstore<v2>(dst, st.ooff[k], o);
+                    } else {
+                        gstore<T>(dst, st.ooff[k], o.x);
+                        if (st.ostore[k] == 2) gstore<T>(dst, st.ooff[k] + (unsigned)sizeof(T), o.y);
+                    }
+                }
+            }
+        NDWT_SEND
+    }
+    template <int R>
+    static NDWT_DEV void zdispatch(int r, State& st, const RegTaps& tp, const Args& a, long long obase, int z, bool emit, int tid) {
+        if constexpr (R < L) {
+            if (r == R) zsyn<R>(st, tp, a, obase, z, emit, tid);
+            else zdispatch<R + 1>(r, st, tp, a, obase, z, emit, tid);
+        }
+    }
+
+#if defined(NDWT_STAMPS) && !defined(NDWT_HOST_EMU)
+    // diagnostic build: the clock at six points of planes 100 and 101, every wave of every workgroup (a timeline, not sums;
+    // no scheduling fences: the product kernel's overlaps stay) -- tools/timeline_inv.py
+#define NDWT_TL(slot) if (a.stamps && (p == 100 || p == 101)) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); \
+        if (threadIdx.x % 64 == 0) a.stamps[(((long long)bid * (NT / 64) + threadIdx.x / 64) * 2 + (p - 100)) * 8 + (slot)] = (long long)t_; }
+#else
+#define NDWT_TL(slot)
+#endif
+
+    template <class Exec> static NDWT_DEV void block(Exec& ex, Shared& sh, const Args& a, const Taps& tpm, int bid) {
+        RegTaps tp;
+        load_taps(tp, tpm);
+        const TileCoord tc = decode_tile(a, bid, TX, TY);
+        const long long ibase = batch_base(tc.batch, a.bsplit, a.in_bstride, a.in_bstride2);
+        const long long obase = batch_base(tc.batch, a.bsplit, a.out_bstride, a.out_bstride2);
+        const int zsh = tc.batch * a.zbs;
+        const int nsteps = tc.zend - tc.zbeg;
+        const int nplanes = nsteps + L - 1;              // planes zbeg-LH .. zend-1+RH
+        ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+            setup(st, a, tc, tid);
+            load_raw<0>(st, a, ibase, tc.zbeg - LH, zsh);
+            if constexpr (DEPTH == 2) {
+                if (nplanes > 1) load_raw<1>(st, a, ibase, tc.zbeg - LH + 1, zsh);
+            }
+        });
+        // the y and z stages of plane p (x-synthesised tile in xs[p & 1]) at raised priority: they are short and end in the
+        // plane's store, and under oldest-first arbitration the youngest waves' store waits behind the older waves' queued loads
+        auto yz = [&](int p) __attribute__((always_inline)) {
+            const int s = p - (L - 1);                   // output plane this input plane completes (if >= 0)
+            NDWT_SETPRIO(1);
+            ex.each([&](int tid, State& st) __attribute__((always_inline)) { ysyn(st, sh, tp, p & 1, tid); });
+            NDWT_TL(3)
+            ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+                zdispatch<0>((p + 1) % L, st, tp, a, obase, tc.zbeg + s, s >= 0, tid);
+            });
+            NDWT_SETPRIO(0);
+            NDWT_TL(4)
+        };
+        if constexpr (DEPTH == 1) {
+            // per plane:  x-synth(p) from registers -> xs[p&1] ; refill with plane p+1 ; barrier ; y/z(p) from xs[p&1]
+            for (int p = 0; p < nplanes; ++p) {
+                NDWT_TL(0)
+                ex.each([&](int, State& st) __attribute__((always_inline)) { shrink_raw<0>(st, a); });
+                ex.each([&](int tid, State& st) __attribute__((always_inline)) { xsyn<0>(ex, st, sh, tp, p & 1, tid); });
+                NDWT_TL(1)
+                ex.each([&](int, State& st) __attribute__((always_inline)) {
+                    if (p + 1 < nplanes) load_raw<0>(st, a, ibase, tc.zbeg - LH + p + 1, zsh);
+                });
+                NDWT_TL(2)
+                ex.barrier();
+                yz(p);
+            }
+        } else {
+            // Two register sets, refilled at TWO DIFFERENT POINTS of the plane.  A wave stalls on its own loads until the pipe
+            // has accepted them; when every wave refills after its x stage the pipe idles from the barrier until the first
+            // x stage ends, and the workgroup then waits for the last wave's loads to be accepted.  Half of the waves refill
+            // at the START of an iteration (the set their previous x stage freed), the others right after their x stage.
+            //   iteration p (parity Q): early waves: set Q <- plane p+2 ; y/z(p) ; x(p+1) from set 1-Q ; late waves: set 1-Q <- plane p+3 ; barrier
+            auto iter = [&](auto q_c, int p) __attribute__((always_inline)) {
+                constexpr int Q = decltype(q_c)::value;
+                NDWT_TL(0)
+                ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+                    if (early_refill(tid) && p + 2 < nplanes) load_raw<Q>(st, a, ibase, tc.zbeg - LH + p + 2, zsh);
+                });
+                NDWT_TL(1)
+                yz(p);
+                if (p + 1 < nplanes) {
+                    ex.each([&](int, State& st) __attribute__((always_inline)) { shrink_raw<1 - Q>(st, a); });
+                    ex.each([&](int tid, State& st) __attribute__((always_inline)) { xsyn<1 - Q>(ex, st, sh, tp, 1 - Q, tid); });
+                    NDWT_TL(2)
+                    ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+                        if (!early_refill(tid) && p + 3 < nplanes) load_raw<1 - Q>(st, a, ibase, tc.zbeg - LH + p + 3, zsh);
+                    });
+                }
+                NDWT_TL(5)
+                ex.barrier();
+            };
+            // prologue: x stage of plane 0; the late waves refill its set with plane 2 (the early ones at the start of iteration 0)
+            ex.each([&](int, State& st) __attribute__((always_inline)) { shrink_raw<0>(st, a); });
+            ex.each([&](int tid, State& st) __attribute__((always_inline)) { xsyn<0>(ex, st, sh, tp, 0, tid); });
+            ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+                if (!early_refill(tid) && 2 < nplanes) load_raw<0>(st, a, ibase, tc.zbeg - LH + 2, zsh);
+            });
+            ex.barrier();
+            for (int p = 0; p < nplanes; p += 2) {
+                iter(std::integral_constant<int, 0>{}, p);
+                if (p + 1 < nplanes) iter(std::integral_constant<int, 1>{}, p + 1);
+            }
         }
     }
 };
@@ -1003,7 +1482,6 @@ template <typename T> struct Fused2Args {
     int ychunk;            // output rows per wave
     int ntx, nyc;          // wave tiles along x, chunks along y
     int y_wrap;            // 1: periodic in y; 0: inputs start `left` rows before local row 0 (slab mode)
-    int dbg;
     int rs;                // elements between rows (n1; a level dilated by s: s * n1, the s row sub-lattices are the batch items)
     T shrink_thr;          // synthesis: shrink input band b on load when bit b of shrink_mask is set
     int shrink_mask, shrink_hard;

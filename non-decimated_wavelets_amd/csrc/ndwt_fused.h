@@ -23,6 +23,10 @@ int launch_inv3_f32(const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, 
 int launch_fwd3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4, int variant, int ew, const void* taps_dev, hipStream_t s);
 int launch_inv3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4, int variant, int ew, const void* taps_dev, hipStream_t s);
 
+// float synthesis of real data with tap stride 1, tap lengths <= 8: the pair-packed kernel (Inv3Y) on a 64 x 32 tile with 1024
+// threads; depth = register sets of band loads (2: staggered refill, aligned volumes only)
+int launch_inv3y_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, const void* taps_dev, hipStream_t s);
+
 // fused 2-D kernels (register-only, one wave per tile)
 int fused2_tile_width(bool inverse, int Lp, int ew);
 int launch_fwd2_f32(const Fused2Args<float>& a, int Lp, bool vec4, int ew, const void* taps_dev, hipStream_t s);

@@ -1,0 +1,28 @@
+// fused 3-D inv level, float, real data, stride 1: the pair-packed lane-shift kernel (Inv3Y), tap lengths 2..8
+#include "ndwt_fused_kernels.h"
+namespace ndwt {
+
+template <int LL, bool V, int DEPTH> static int go(const Fused3Args<float>& a, const void* taps_dev, hipStream_t s) {
+    typedef Inv3Y<float, LL, kInv3YTX, kInv3YTY, 1024, V, 4, DEPTH> K;
+    FusedTapsD unused;
+    unused.Lp = LL;
+    return launch_fused3<K>(a, unused, taps_dev, s);
+}
+
+// depth 2 (two register sets of band loads, staggered refill) is the default; depth 1 serves unaligned volumes and A/B runs
+#define NDWT_INVY_CASE(LL) \
+    case LL:               \
+        return vec4 ? (depth == 2 ? go<LL, true, 2>(a, taps_dev, s) : go<LL, true, 1>(a, taps_dev, s)) : go<LL, false, 1>(a, taps_dev, s);
+
+int launch_inv3y_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, const void* taps_dev, hipStream_t s) {
+    switch (Lp) {
+        NDWT_INVY_CASE(8)
+#ifndef NDWT_INVY_DB4_ONLY
+        NDWT_INVY_CASE(2)
+        NDWT_INVY_CASE(4)
+        NDWT_INVY_CASE(6)
+#endif
+        default: return -1;
+    }
+}
+}  // namespace ndwt

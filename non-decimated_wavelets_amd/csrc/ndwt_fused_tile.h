@@ -24,4 +24,6 @@ template <int V> struct Fused3Tile<double, false, V> { static constexpr int TX =
 template <> struct Fused3Tile<double, false, 1>      { static constexpr int TX = 64, TY = 16, NT = 512, RY = 4, WPE = 2; };   // long filters (db5, db6)
 template <int V> struct Fused3Tile<double, true, V>  { static constexpr int TX = 64, TY = 8, NT = 256, RY = 4, WPE = 2; };
 template <> struct Fused3Tile<double, true, 1>       { static constexpr int TX = 64, TY = 16, NT = 512, RY = 2, WPE = 2; };   // lane-shift kernel (Inv3S): the double default
+// float synthesis default (pair-packed kernel Inv3Y): 64 x 32 tile, 1024 threads, one workgroup per CU
+constexpr int kInv3YTX = 64, kInv3YTY = 32;
 }  // namespace ndwt

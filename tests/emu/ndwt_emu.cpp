@@ -49,6 +49,50 @@ int run(ndwt::Fused3Args<T>& a, const double* lo, const double* hi) {
     return 0;
 }
 
+// the pair-packed float synthesis kernel (Inv3Y): extended tap table
+template <class K, typename T>
+int runY(ndwt::Fused3Args<T>& a, const double* lo, const double* hi) {
+    typename K::Taps tp;
+    for (int ax = 0; ax < 3; ++ax)
+        for (int j = 0; j < K::L; ++j) {
+            tp.lo[ax][j] = (T)lo[ax * ndwt::kMaxTaps + j];
+            tp.hi[ax][j] = (T)hi[ax * ndwt::kMaxTaps + j];
+        }
+    for (int k = 0; k <= K::L; ++k)
+        for (int h = 0; h < 2; ++h) {
+            const int j = k - h;
+            tp.xplo[k][h] = (j >= 0 && j < K::L) ? (T)lo[j] : T(0);
+            tp.xphi[k][h] = (j >= 0 && j < K::L) ? (T)hi[j] : T(0);
+        }
+    const int nblocks = a.ntx * a.nty * a.nzc * a.nbatch;
+    for (int b = 0; b < nblocks; ++b) {
+        std::unique_ptr<typename K::Shared> sh(new typename K::Shared);
+        EmuExec<typename K::State, K::NT> ex;
+        K::block(ex, *sh, a, tp, b);
+    }
+    return 0;
+}
+
+template <typename T, int TX, int TY, int NT, bool ALL, int DEPTH>
+int dispatchY(int Lp, int vec4, ndwt::Fused3Args<T>& a, const double* lo, const double* hi) {
+#define CASEY(LL)                                                                   \
+    case LL:                                                                        \
+        return vec4 ? runY<ndwt::Inv3Y<T, LL, TX, TY, NT, true, 2, DEPTH>, T>(a, lo, hi)  \
+                    : runY<ndwt::Inv3Y<T, LL, TX, TY, NT, false, 2, DEPTH>, T>(a, lo, hi);
+    if constexpr (ALL) {
+        switch (Lp) {
+            CASEY(2) CASEY(4) CASEY(6) CASEY(8) CASEY(12)
+            default: return -1;
+        }
+    } else {
+        switch (Lp) {
+            CASEY(8)
+            default: return -1;
+        }
+    }
+#undef CASEY
+}
+
 template <typename T, template <typename, int, int, int, int, int, bool, int, int> class KIND, int TX, int TY, int NT, int RY, bool ALL, int EW = 1>
 int dispatch(int Lp, int vec4, ndwt::Fused3Args<T>& a, const double* lo, const double* hi) {
 #define CASE(LL)                                                              \
@@ -139,6 +183,18 @@ int emu3(int Lp, int vec4, const T* in, T* out, int n1, int n2, int n3, int nbat
         } else {
             geometry(PF::TX, PF::TY);
             return dispatch<T, ndwt::Fwd3, PF::TX, PF::TY, PF::NT, PF::RY, false, 2>(Lp, vec4, a, lo, hi);
+        }
+    }
+    if constexpr (INV && sizeof(T) == 4) {   // pair-packed synthesis (Inv3Y): variant 5 one register set of band loads, 8 two (staggered refill)
+        if (variant == 5 || variant == 8) {
+            if (small_tile) {
+                geometry(16, 8);
+                return variant == 5 ? dispatchY<T, 16, 8, 128, true, 1>(Lp, vec4, a, lo, hi)
+                                    : dispatchY<T, 16, 8, 512, true, 2>(Lp, vec4, a, lo, hi);   // 8 waves: both refill schedules run
+            }
+            geometry(ndwt::kInv3YTX, ndwt::kInv3YTY);
+            return variant == 5 ? dispatchY<T, ndwt::kInv3YTX, ndwt::kInv3YTY, 1024, false, 1>(Lp, vec4, a, lo, hi)
+                                : dispatchY<T, ndwt::kInv3YTX, ndwt::kInv3YTY, 1024, false, 2>(Lp, vec4, a, lo, hi);
         }
     }
     if (small_tile) {   // a second tile shape exercises different item/lane mappings

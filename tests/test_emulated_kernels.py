@@ -100,6 +100,33 @@ def test_emulated_fused3_synthesis(emu, sizes, wn, vec4, zchunk, small, l2):
             assert np.abs(got - want).max() <= tol * max(np.abs(want).max(), 1.0)
 
 
+CASES_Y = [
+    # sizes (n1,n2,n3),      wavelets,               vec4,  zchunk, small_tile   (padding (Lp - len) / 2 even on every axis)
+    ((16, 9, 7), ("db1", "db3", "db1"), True, 0, True),
+    ((13, 10, 9), ("db2", "db2", "db2"), False, 4, True),
+    ((20, 17, 12), ("db4", "db4", "db4"), True, 5, True),
+    ((24, 19, 11), ("db6", "db2", "db4"), True, 0, True),        # two-hop lane shifts
+    ((68, 39, 9), ("db4", "db4", "db4"), True, 0, False),        # production tile shape (db4 only): ragged in x and y
+    ((70, 60, 10), ("db2", "db2", "db4"), False, 6, False),
+]
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("sizes,wn,vec4,zchunk,small", CASES_Y)
+@pytest.mark.parametrize("l2", [0, 1])
+def test_emulated_pair_packed_synthesis(emu, sizes, wn, vec4, zchunk, small, l2):
+    """Inv3Y, the float synthesis default: x pairs on packed FMAs, high-pass taps derived from the low-pass ones by operand
+    modifiers, loads only from lanes that hold a row; variant 5 = one register set of band loads, 8 = two with staggered refill"""
+    rng = np.random.default_rng(12)
+    c = rng.standard_normal(tuple(sizes) + (8,))
+    filt = [orc.wave_filters(w) for w in wn]
+    want = orc.spatial_level_rec(c, filt, l2)
+    for variant in ((5, 8) if vec4 else (5,)):
+        got = _run(emu, c, wn, l2, True, np.float32, vec4, zchunk, small, variant=variant)
+        assert np.isfinite(got).all(), variant
+        assert np.abs(got - want).max() <= 2e-6 * max(np.abs(want).max(), 1.0), variant
+
+
 def _run2(emu, arr, wnames, l2, inverse, dtype, vec4, ychunk, cplx=False, shrink=(0.0, 0, 0), dil=1):
     Ls = [len(orc.wave_filters(w)[0]) for w in wnames]
     Lp = max(Ls)
