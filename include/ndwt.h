@@ -72,6 +72,15 @@ int ndwt_level_from_bands(int ndim, int64_t bands); /* returns level >= 1, or -1
  * largest level dec/rec will be asked for (sizes the scratch); device = HIP device ordinal. */
 int ndwt_plan_create(ndwt_plan** plan, int ndim, const int64_t* dims, const char* const* wnames, int dtype,
                      int complexity, int pres_l2_norm, int dilation, int max_level, int device);
+/* Plan for ONE SLAB of a volume sharded on its outermost axis (the *_slab entry points below): dims describe the local slab,
+ * global_outer is the length of the sharded axis of the whole volume.  The reference's length check (nd_dwt_3D.m:277-286:
+ * filter <= axis) applies to the WHOLE axis: a slab may be thinner than the filter (cfg5: 32 frames over 8 ranks = 4, db4 = 8
+ * taps) -- the slab kernels read halo planes and never wrap.  ndwt_dec / ndwt_rec (periodic on every axis) refuse such a plan
+ * when the local length is shorter than the filter. */
+int ndwt_plan_create_slab(ndwt_plan** plan, int ndim, const int64_t* dims_local, int64_t global_outer, const char* const* wnames,
+                          int dtype, int complexity, int pres_l2_norm, int dilation, int max_level, int device);
+/* A plan owns scratch (the approximation ping-pong between levels, temporaries): use it from ONE host thread and ONE stream
+ * at a time.  Calls on different streams must be ordered by the caller (an event), or use one plan per stream. */
 int ndwt_plan_destroy(ndwt_plan* plan);
 int ndwt_plan_set_path(ndwt_plan* plan, int path); /* NDWT_PATH_* */
 /* which kernels a level of this plan runs: writes a short static string such as "fused3d", "fused2d",

@@ -33,7 +33,9 @@ class Plan:
     """Thin RAII wrapper over ndwt_plan (include/ndwt.h)."""
 
     def __init__(self, dims, wnames, dtype, complex_interleaved=False, pres_l2_norm=False, dilation="reference",
-                 max_level=1, device=0):
+                 max_level=1, device=0, global_outer=None):
+        """global_outer: length of the outermost axis of the WHOLE volume when `dims` describe one slab of it (multi-GPU):
+        the reference's filter-length check then applies to the whole axis, a slab may be thinner than the filter"""
         self.dims = [int(d) for d in dims]
         self.ndim = len(self.dims)
         self.wnames = list(wnames)
@@ -45,9 +47,13 @@ class Plan:
         names_c = (ctypes.c_char_p * self.ndim)(*[w.encode() for w in self.wnames])
         dt = L.NDWT_F32 if dtype in (torch.float32, np.float32, "single") else L.NDWT_F64
         dil = {"reference": L.NDWT_DILATION_REFERENCE, "atrous": L.NDWT_DILATION_ATROUS}[dilation]
-        L.check(L.lib().ndwt_plan_create(ctypes.byref(self._h), self.ndim, dims_c, names_c, dt,
-                                         L.NDWT_COMPLEX_INTERLEAVED if complex_interleaved else L.NDWT_REAL,
-                                         int(bool(pres_l2_norm)), dil, self.max_level, self.device))
+        cplx = L.NDWT_COMPLEX_INTERLEAVED if complex_interleaved else L.NDWT_REAL
+        if global_outer is None:
+            L.check(L.lib().ndwt_plan_create(ctypes.byref(self._h), self.ndim, dims_c, names_c, dt, cplx,
+                                             int(bool(pres_l2_norm)), dil, self.max_level, self.device))
+        else:
+            L.check(L.lib().ndwt_plan_create_slab(ctypes.byref(self._h), self.ndim, dims_c, int(global_outer), names_c, dt, cplx,
+                                                  int(bool(pres_l2_norm)), dil, self.max_level, self.device))
 
     def __del__(self):
         try:
@@ -239,12 +245,14 @@ class _NdDwtBase:
         return torch.device("cuda", torch.cuda.current_device())
 
     def _plan(self, is_complex, level, dev):
-        key = (is_complex, dev.index or 0)
+        # one plan per (data kind, device, stream): a plan owns scratch and serves one stream at a time (include/ndwt.h)
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        key = (is_complex, idx, _current_stream(dev))
         p = self._plans.get(key)
         if p is None or p.max_level < level:
             real_dt = torch.float32 if self.precision.lower() == "single" else torch.float64
             p = Plan(self.sizes, self.wname[: self.NDIM], real_dt, is_complex, self.pres_l2_norm, self.dilation,
-                     max_level=max(level, 3), device=dev.index or 0)
+                     max_level=max(level, 3), device=idx)
             self._plans[key] = p
         return p
 

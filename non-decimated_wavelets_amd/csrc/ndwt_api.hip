@@ -90,6 +90,8 @@ struct ndwt_plan {
     int profiling;
     std::vector<ProfRec>* prof;
     long long* stamps;                 // diagnostic builds (-DNDWT_STAMPS): device buffer for the per-wave phase cycle sums
+    int thin_slab;                     // slab plan whose outer axis is shorter than its filter: slab entry points only
+    std::vector<hipEvent_t>* ev_pool;  // profiling events, reused
 };
 
 static int ensure_tmp(ndwt_plan* p, size_t bytes) {
@@ -106,16 +108,29 @@ static int ensure_tmp(ndwt_plan* p, size_t bytes) {
     return NDWT_OK;
 }
 
+// Events come from a pool owned by the plan (get_profile returns them to it), and a launch that did not happen
+// (no instantiation: rc < 0, the caller falls through to another kernel) leaves no record.
+static bool prof_event(const ndwt_plan* p, hipEvent_t* e) {
+    if (!p->ev_pool->empty()) { *e = p->ev_pool->back(); p->ev_pool->pop_back(); return true; }
+    return hipEventCreate(e) == hipSuccess;
+}
 static void prof_begin(const ndwt_plan* p, int kind, hipStream_t s) {
     if (!p->profiling) return;
     ProfRec r;
     r.kind = kind;
-    if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
+    if (!prof_event(p, &r.start)) return;
+    if (!prof_event(p, &r.stop)) { p->ev_pool->push_back(r.start); return; }
     (void)hipEventRecord(r.start, s);
     p->prof->push_back(r);
 }
-static void prof_end(const ndwt_plan* p, hipStream_t s) {
+static void prof_end(const ndwt_plan* p, hipStream_t s, int rc = 0) {
     if (!p->profiling || p->prof->empty()) return;
+    if (rc != 0) {                                        // nothing was launched: drop the record
+        p->ev_pool->push_back(p->prof->back().start);
+        p->ev_pool->push_back(p->prof->back().stop);
+        p->prof->pop_back();
+        return;
+    }
     (void)hipEventRecord(p->prof->back().stop, s);
 }
 
@@ -188,7 +203,7 @@ static int axis_pass(const ndwt_plan* p, bool synthesis, int axis, const long lo
         m.nchunks = (int)((m.n + chunk - 1) / chunk);
         prof_begin(p, synthesis ? NDWT_KERNEL_AXIS_SYNTHESIS : NDWT_KERNEL_AXIS_ANALYSIS, s);
         int rc = launch_march<T>(synthesis, f.len, m, synthesis ? f.syn_lo : f.ana_lo, synthesis ? f.syn_hi : f.ana_hi, s);
-        prof_end(p, s);
+        prof_end(p, s, rc);
         if (rc == 0) return NDWT_OK;
         if (rc > 0) return fail(NDWT_ERR_HIP, "march kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         // rc < 0: no instantiation / grid too large -> fall through to the element-wise kernel
@@ -205,7 +220,7 @@ static int axis_pass(const ndwt_plan* p, bool synthesis, int axis, const long lo
                           (synthesis || aligned_vec4<T>(out1));
         prof_begin(p, synthesis ? NDWT_KERNEL_AXIS_SYNTHESIS : NDWT_KERNEL_AXIS_ANALYSIS, s);
         int rc = launch_axisx<T>(synthesis, f.len, (int)p->comp, x, v4ok, synthesis ? f.syn_lo : f.ana_lo, synthesis ? f.syn_hi : f.ana_hi, s);
-        prof_end(p, s);
+        prof_end(p, s, rc);
         if (rc == 0) return NDWT_OK;
         if (rc > 0) return fail(NDWT_ERR_HIP, "contiguous-axis kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     }
@@ -340,15 +355,19 @@ template <> int launch3<double>(bool inverse, const Fused3Args<double>& a, const
 }
 
 namespace ndwt {
-void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int* TY, int dil) {
-    (void)Lp;
+// the tile the launcher of ndwt_fused_kernels.h will pick (ew = scalars per x element: 1 real, 2 interleaved complex or a level
+// dilated by 2, 4 a level dilated by 4).  The A/B variants exist for real, undilated data only.
+void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int* TY, int ew) {
+    if (ew != 1) variant = 0;
     *TX = 64;
-    *TY = f64 ? 8 : 16;
-    if (!f64 && inverse && !(variant == 3 && Lp == 8)) *TY = 32;   // float synthesis default: tall tile
-    if (!f64 && !inverse && variant == 2 && (Lp == 8 || Lp == 12)) *TY = 32;
-    if (!f64 && inverse && dil == 4) *TY = 16;                                         // x taps over 4 scalars: 64x16 / 512 threads
-    if (f64 && !inverse && Lp >= 10) *TY = 16;                                         // double analysis, db5/db6: 512 threads
-    if (f64 && inverse && !(variant == 3 && Lp == 8)) *TY = 16;                        // double synthesis default: lane-shift kernel, 64x16
+    if (!inverse) {
+        *TY = f64 ? (Lp >= 10 ? 16 : 8) : 16;                                     // double, db5/db6: 512 threads
+        if (!f64 && variant == 2 && (Lp == 8 || Lp == 12)) *TY = 32;            // float, tall tile (A/B)
+    } else if (f64) {
+        *TY = (variant == 3 && Lp == 8) ? 8 : 16;                                 // lane-shift kernel 64x16; variant 3 = LDS kernel
+    } else {
+        *TY = (variant == 3 && Lp == 8) ? 16 : (ew == 4 ? 16 : 32);              // tall tile; x taps over 4 scalars: 64x16 / 512 threads
+    }
 }
 }  // namespace ndwt
 
@@ -390,12 +409,13 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     for (int b = 0; b < nout; ++b) { a.out[b] = out[b]; vec4 = vec4 && aligned_vec4<T>(out[b]); }
     int TX = 0, TY = 0;
     const int variant = inverse ? p->variant_inv : p->variant_fwd;
-    fused3_tile_shape(sizeof(T) == 8, inverse, variant, Lp, &TX, &TY, dil);
+    const int ew = dil > 1 ? dil : (int)p->comp;
+    fused3_tile_shape(sizeof(T) == 8, inverse, ew != 1 ? 0 : variant, Lp, &TX, &TY, ew);
     const int zc_force = p->zchunk_dir[inverse ? 1 : 0] > 0 ? p->zchunk_dir[inverse ? 1 : 0] : p->force_zchunk;
     // One round of workgroups that all fit on the chip at once beats several partial rounds (measured, 512^3 float
     // analysis: 512 workgroups 0.88 ms, 1024: 1.09 ms, 2048: 0.99 ms; 256^3 double synthesis: 256 workgroups 0.36 ms,
     // 640: 0.48 ms).  Workgroups per CU: synthesis 1 (1024 threads / 94 KB of LDS), analysis 2 (3 fit, 2 run faster).
-    const bool small_inv = inverse && sizeof(T) == 4 && variant == 3 && Lp == 8;   // 256-thread A/B variant
+    const bool small_inv = inverse && sizeof(T) == 4 && ew == 1 && variant == 3 && Lp == 8;   // 256-thread A/B variant
     const int per_cu = inverse ? (small_inv ? 3 : 1) : (dil == 4 ? 1 : 2);
     const int target = p->target_blocks > 0 ? p->target_blocks : p->num_cus * per_cu;
     // analysis (2-3 workgroups per CU): more tiles than resident slots -> about 8 workgroups per CU; synthesis (1 per CU,
@@ -416,8 +436,8 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     if constexpr (sizeof(T) == 4) {
         if (inverse && dil == 1 && inv3y_eligible(p, Lp, a)) rc = launch_inv3y_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s);
     }
-    if (rc == -1) rc = launch3<T>(inverse, a, t, vec4, variant, dil > 1 ? dil : (int)p->comp, td, s);
-    prof_end(p, s);
+    if (rc == -1) rc = launch3<T>(inverse, a, t, vec4, ew != 1 ? 0 : variant, ew, td, s);
+    prof_end(p, s, rc);
     if (rc == -1) return fail(NDWT_ERR_UNSUPPORTED, "no fused kernel instantiated for tap length %d", Lp);
     if (rc != 0) return fail(NDWT_ERR_HIP, "fused kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     return NDWT_OK;
@@ -466,7 +486,7 @@ static int fused2_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     if (!td) return fail(NDWT_ERR_UNSUPPORTED, "plan has no device tap table");
     prof_begin(p, inverse ? NDWT_KERNEL_FUSED_SYNTHESIS : NDWT_KERNEL_FUSED_ANALYSIS, s);
     int rc = launch2<T>(inverse, a, Lp, vec4, ew2, td, s);
-    prof_end(p, s);
+    prof_end(p, s, rc);
     if (rc == -1) return fail(NDWT_ERR_UNSUPPORTED, "no fused 2-D kernel instantiated for tap length %d", Lp);
     if (rc != 0) return fail(NDWT_ERR_HIP, "fused 2-D kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     return NDWT_OK;
@@ -629,6 +649,8 @@ static int check_level(const ndwt_plan* p, int level) {
     if (!p) return fail(NDWT_ERR_INVALID_ARG, "null plan");
     if (level < 1 || level > p->max_level)
         return fail(NDWT_ERR_INVALID_ARG, "level %d outside 1..max_level=%d of this plan", level, p->max_level);
+    if (p->thin_slab)
+        return fail(NDWT_ERR_FILTER_TOO_LONG, "this slab plan is thinner than its outer-axis filter: only the *_slab entry points apply");
     if (p->dilation == NDWT_DILATION_ATROUS) {
         for (int a = 0; a < p->ndim; ++a) {
             long long span = (long long)(p->filt[a].len - 1) * (1LL << (level - 1)) + 1;
@@ -797,8 +819,8 @@ int ndwt_level_from_bands(int ndim, int64_t bands) {
     return (int)(1 + (bands - nb) / (nb - 1));
 }
 
-int ndwt_plan_create(ndwt_plan** plan, int ndim, const int64_t* dims, const char* const* wnames, int dtype, int complexity,
-                     int pres_l2_norm, int dilation, int max_level, int device) {
+static int plan_create_impl(ndwt_plan** plan, int ndim, const int64_t* dims, long long global_outer, const char* const* wnames, int dtype,
+                            int complexity, int pres_l2_norm, int dilation, int max_level, int device) {
     if (!plan) return fail(NDWT_ERR_INVALID_ARG, "null plan pointer");
     *plan = nullptr;
     if (ndim < 1 || ndim > NDWT_MAX_DIMS) return fail(NDWT_ERR_INVALID_ARG, "ndim must be 1..4");
@@ -821,6 +843,7 @@ int ndwt_plan_create(ndwt_plan** plan, int ndim, const int64_t* dims, const char
     p->comp = complexity == NDWT_COMPLEX_INTERLEAVED ? 2 : 1;
     p->target_blocks = 0;
     p->prof = new std::vector<ProfRec>();
+    p->ev_pool = new std::vector<hipEvent_t>();
     p->fp64_fused = 1;   // measured: 256^3 fp64 db4 L3 2.5 ms fused (LDS analysis + lane-shift synthesis) vs 4.1 ms per-axis
     if (const char* v = getenv("NDWT_FP64_FUSED")) p->fp64_fused = atoi(v);
     if (const char* v = getenv("NDWT_VARIANT_FWD")) p->variant_fwd = atoi(v);
@@ -830,14 +853,18 @@ int ndwt_plan_create(ndwt_plan** plan, int ndim, const int64_t* dims, const char
     static const char* ordn[4] = {"First", "Second", "Third", "Fourth"};
     p->vol = p->comp;
     for (int a = 0; a < ndim; ++a) {
-        if (dims[a] < 1) { delete p->prof; delete p; return fail(NDWT_ERR_INVALID_ARG, "dims[%d] must be >= 1", a); }
+        if (dims[a] < 1) { delete p->prof; delete p->ev_pool; delete p; return fail(NDWT_ERR_INVALID_ARG, "dims[%d] must be >= 1", a); }
         const int K = parse_wavelet(wnames[a]);
-        if (!K) { delete p->prof; delete p; return fail(NDWT_ERR_UNKNOWN_WAVELET, "Unknown Wavelet Name"); }
+        if (!K) { delete p->prof; delete p->ev_pool; delete p; return fail(NDWT_ERR_UNKNOWN_WAVELET, "Unknown Wavelet Name"); }
         p->dims[a] = dims[a];
         p->order[a] = K;
         p->filt[a] = make_axis_filter(K, p->l2 != 0);
-        if (p->filt[a].len > dims[a]) {   // nd_dwt_3D.m:277-286
+        // nd_dwt_3D.m:277-286; for a slab plan the check is on the whole sharded axis, not on the local planes
+        const long long axis_len = (a == ndim - 1 && global_outer > 0) ? global_outer : dims[a];
+        if (a == ndim - 1 && global_outer > 0 && p->filt[a].len > dims[a]) p->thin_slab = 1;
+        if (p->filt[a].len > axis_len) {
             delete p->prof;
+            delete p->ev_pool;
             delete p;
             return fail(NDWT_ERR_FILTER_TOO_LONG, "%s Dimension of Data is shorter than the wavelet filter being used", ordn[a]);
         }
@@ -846,10 +873,11 @@ int ndwt_plan_create(ndwt_plan** plan, int ndim, const int64_t* dims, const char
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
         delete p->prof;
+        delete p->ev_pool;
         delete p;
         return fail(NDWT_ERR_NO_DEVICE, "no usable HIP device (requested %d of %d): this engine has no CPU path", device, ndev);
     }
-    if (hipSetDevice(device) != hipSuccess) { delete p->prof; delete p; return fail(NDWT_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device); }
+    if (hipSetDevice(device) != hipSuccess) { delete p->prof; delete p->ev_pool; delete p; return fail(NDWT_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device); }
     {
         hipDeviceProp_t prop;
         p->num_cus = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
@@ -900,6 +928,19 @@ int ndwt_plan_create(ndwt_plan** plan, int ndim, const int64_t* dims, const char
     return NDWT_OK;
 }
 
+int ndwt_plan_create(ndwt_plan** plan, int ndim, const int64_t* dims, const char* const* wnames, int dtype, int complexity,
+                     int pres_l2_norm, int dilation, int max_level, int device) {
+    return plan_create_impl(plan, ndim, dims, -1, wnames, dtype, complexity, pres_l2_norm, dilation, max_level, device);
+}
+
+int ndwt_plan_create_slab(ndwt_plan** plan, int ndim, const int64_t* dims_local, int64_t global_outer, const char* const* wnames,
+                          int dtype, int complexity, int pres_l2_norm, int dilation, int max_level, int device) {
+    if (ndim >= 1 && ndim <= NDWT_MAX_DIMS && dims_local && global_outer < dims_local[ndim - 1])
+        return fail(NDWT_ERR_INVALID_ARG, "global_outer (%lld) is shorter than the local slab (%lld)", (long long)global_outer,
+                    (long long)dims_local[ndim - 1]);
+    return plan_create_impl(plan, ndim, dims_local, global_outer, wnames, dtype, complexity, pres_l2_norm, dilation, max_level, device);
+}
+
 int ndwt_plan_destroy(ndwt_plan* p) {
     if (!p) return NDWT_OK;
     (void)hipSetDevice(p->device);
@@ -912,6 +953,10 @@ int ndwt_plan_destroy(ndwt_plan* p) {
     if (p->prof) {
         for (auto& r : *p->prof) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
         delete p->prof;
+    }
+    if (p->ev_pool) {
+        for (auto e : *p->ev_pool) (void)hipEventDestroy(e);
+        delete p->ev_pool;
     }
     delete p;
     return NDWT_OK;
@@ -935,8 +980,8 @@ int ndwt_plan_get_profile(ndwt_plan* p, int kind, double* total_ms, int64_t* lau
         if (r.kind != kind) { keep.push_back(r); continue; }
         float ms = 0;
         if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) { tot += ms; ++n; }
-        (void)hipEventDestroy(r.start);
-        (void)hipEventDestroy(r.stop);
+        p->ev_pool->push_back(r.start);
+        p->ev_pool->push_back(r.stop);
     }
     p->prof->swap(keep);
     *total_ms = tot;

@@ -16,7 +16,7 @@ struct FusedTapsD {       // per axis (0 = x, 1 = y, 2 = z), zero-padded to Lp, 
 };
 
 // tile shape a variant uses (for the launch geometry)
-void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int* TY, int dil);
+void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int* TY, int ew);
 
 int launch_fwd3_f32(const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, int variant, int ew, const void* taps_dev, hipStream_t s);
 int launch_inv3_f32(const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, int variant, int ew, const void* taps_dev, hipStream_t s);

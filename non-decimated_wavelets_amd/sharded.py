@@ -37,10 +37,15 @@ def partition(n: int, world: int):
 class HipSlabEngine:
     """Local compute of one slab on one GPU through include/ndwt.h (slab entry points)."""
 
-    def __init__(self, wnames, local_dims, dtype, pres_l2_norm, dilation, device):
+    def __init__(self, wnames, local_dims, dtype, pres_l2_norm, dilation, device, global_outer=None):
         from .api import Plan
-        self.plan = Plan(local_dims, wnames, dtype, False, pres_l2_norm, dilation, max_level=1, device=device.index or 0)
-        self.device = device
+        # a slab plan: the filter-length check of the reference applies to the whole sharded axis (global_outer), the local
+        # slab may be thinner than the filter (cfg5: 4 frames per rank, 8 taps)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        self.plan = Plan(local_dims, wnames, dtype, False, pres_l2_norm, dilation, max_level=1, device=idx,
+                         global_outer=global_outer if global_outer is not None else local_dims[-1])
+        self.device = torch.device("cuda", idx)
+        self._parts = None
         self.dtype = dtype
         self.local_dims = list(local_dims)
         # split-halo analysis + zero-extended synthesis entry points (fused 3-D kernels only)
@@ -103,7 +108,10 @@ class HipSlabEngine:
         from ONE launch (two runs of max(sa, sb) planes at the two ends of the zero-extended result)."""
         _, _, sb, sa = self.halo(stride)
         n, m = ins_local[0].shape[0], max(sa, sb)
-        buf = ins_local[0].new_empty((2, m) + tuple(ins_local[0].shape[1:]))
+        shape = (2, m) + tuple(ins_local[0].shape[1:])
+        if self._parts is None or tuple(self._parts.shape) != shape or self._parts.dtype != ins_local[0].dtype:
+            self._parts = ins_local[0].new_empty(shape)
+        buf = self._parts
         self.plan.synthesis_level_slab_runs([t.data_ptr() for t in ins_local], n, 0, n + sa + sb - m, 2, m, buf.data_ptr(), stride,
                                             self._stream())
         return buf[0, :sa], buf[1, m - sb:]
@@ -130,13 +138,14 @@ class ShardedNdDwt:
         self.inner_shape = tuple(reversed(self.sizes[:-1]))          # kernel order of the unsharded axes
         local_dims = self.sizes[:-1] + [self.n_local]
         self.engine = engine if engine is not None else HipSlabEngine(self.wname, local_dims, self.dtype, pres_l2_norm,
-                                                                     dilation, self.device)
+                                                                     dilation, self.device, global_outer=self.n_outer)
         self.plan = getattr(self.engine, "plan", None)
         if synthesis_scheme == "auto":
             synthesis_scheme = "scatter" if getattr(self.engine, "supports_scatter", False) else "gather"
         self.scheme = synthesis_scheme
         self.nb = 1 << self.d
         self._exchange_cache = {}
+        self._bufs = {}                         # scratch tensors reused across calls (halo margins, partial sums, receive buffers)
         # gloo moves host memory only: GPU slabs exchanged over gloo (debugging / rehearsing ranks that share one GPU) are
         # staged through host copies.  RCCL ("nccl") sends the device buffers as they are.
         self._host_stage = bool(self.device.type == "cuda" and dist.is_initialized() and dist.get_backend(group) == "gloo")
@@ -150,6 +159,16 @@ class ShardedNdDwt:
             if lo <= g < hi:
                 return r
         raise AssertionError(g)
+
+    def _buf(self, name, shape, like):
+        """scratch tensor `name` of this shape (dtype / device of `like`), allocated once and reused by later calls.  Only
+        intermediates live here: what dec() / rec() return is always a fresh tensor."""
+        shape = tuple(int(v) for v in shape)
+        t = self._bufs.get(name)
+        if t is None or tuple(t.shape) != shape or t.dtype != like.dtype or t.device != like.device:
+            t = torch.empty(shape, dtype=like.dtype, device=like.device)
+            self._bufs[name] = t
+        return t
 
     def _plan_exchange(self, before, after):
         """Who needs which planes.  Returns contiguous segments (dst_rank, side, src_rank, k0, l0, count) in a
@@ -245,7 +264,10 @@ class ShardedNdDwt:
                     ops.append(dist.P2POp(dist.isend, part, self._global_rank(p), self.group))
             elif p == self.rank:
                 ref = parts[side]
-                buf = torch.empty([n] + list(ref.shape[1:]), dtype=ref.dtype, device="cpu" if self._host_stage else ref.device)
+                if self._host_stage:
+                    buf = torch.empty([n] + list(ref.shape[1:]), dtype=ref.dtype, device="cpu")
+                else:
+                    buf = self._buf(("scatter_recv", q, side, k0), [n] + list(ref.shape[1:]), ref)
                 ops.append(dist.P2POp(dist.irecv, buf, self._global_rank(q), self.group))
                 adds_recv.append((l0, n, buf))
         works = dist.batch_isend_irecv(ops) if ops else []
@@ -266,55 +288,61 @@ class ShardedNdDwt:
 
     # --------------------------------------------------------------------------------- transform
     def dec(self, x_local, level):
-        """x_local: (n_local, ..., n1) -> (bands, n_local, ..., n1); band order of the reference (nddwt.c:210)."""
+        """x_local: (n_local, ..., n1) -> (bands, n_local, ..., n1); band order of the reference (nddwt.c:210).
+
+        The approximation band of every level lives in a scratch buffer [halo_before | slab | halo_after] whose margins
+        receive the neighbours' planes in place, so no haloed copy is assembled (the first level copies x once; engines
+        with the split-halo entry point read x and the two received halo buffers from where they are)."""
         nb, nbt = self.nb, self.nb + (self.nb - 1) * (level - 1)
         x_local = x_local.to(self.dtype).contiguous()
         y = x_local.new_empty((nbt,) + tuple(x_local.shape))
-        cur, cur_buf = x_local, None          # cur_buf: [halo | cur | halo] buffer when cur was produced with margins
-        spare = [None, None]
         n, inner = self.n_local, tuple(x_local.shape[1:])
+        split = bool(hasattr(self.engine, "analysis_split") and getattr(self.engine, "supports_split",
+                                                                     getattr(self.engine, "supports_scatter", False)))
+        cur, cur_buf = x_local, None          # cur_buf: the [halo | cur | halo] buffer cur lives in (None: bare tensor)
         for lev in range(1, level + 1):
             s = self._stride(lev)
             ab, aa, _, _ = self.engine.halo(s)
             overlap = self.overlap and n > ab + aa
+            if cur_buf is None and not split:
+                # engines that need the haloed slab contiguous: the level's input moves into a margin buffer once
+                cur_buf = self._buf(("ana_in", lev & 1), (ab + n + aa,) + inner, x_local)
+                cur_buf[ab:ab + n].copy_(cur)
+                cur = cur_buf[ab:ab + n]
+            # where this level's approximation goes: the final band 0, or the margin buffer of the next level
             a_buf = None
             if lev == level:
                 a_out = y[0]
-            elif overlap and hasattr(self.engine, "analysis_ends"):
-                # the next level's input is produced inside a buffer with room for its halo planes on both sides
-                ab2, aa2 = self.engine.halo(self._stride(lev + 1))[:2]
-                k = (lev - 1) & 1
-                if spare[k] is None or spare[k].shape[0] != ab2 + n + aa2:
-                    spare[k] = x_local.new_empty((ab2 + n + aa2,) + inner)
-                a_buf = spare[k]
-                a_out = a_buf[ab2:ab2 + n]
+            elif split and not (overlap and hasattr(self.engine, "analysis_ends")):
+                a_out = self._buf(("ana_plain", lev & 1), (n,) + inner, x_local)
             else:
-                k = (lev - 1) & 1
-                if spare[k] is None or spare[k].shape[0] != n:
-                    spare[k] = torch.empty_like(x_local)
-                a_out = spare[k]
+                ab2, aa2 = self.engine.halo(self._stride(lev + 1))[:2]
+                a_buf = self._buf(("ana_in", (lev + 1) & 1), (ab2 + n + aa2,) + inner, x_local)
+                a_out = a_buf[ab2:ab2 + n]
             outs = [a_out] + [y[1 + (nb - 1) * (level - lev) + (b - 1)] for b in range(1, nb)]
+            if cur_buf is not None:
+                hb_dst, ha_dst = cur_buf[:ab], cur_buf[ab + n:]
+            else:
+                hb_dst = self._buf(("halo_b", lev & 1), (ab,) + inner, x_local)
+                ha_dst = self._buf(("halo_a", lev & 1), (aa,) + inner, x_local)
             if overlap:
                 # interior planes [ab, n-aa) read the slab only: run them while the halo planes travel
-                if cur_buf is not None:
-                    hb, ha, pending = self._start_fetch_halo(cur, 0, ab, aa, cur_buf[:ab], cur_buf[ab + n:])
-                else:
-                    hb, ha, pending = self._start_fetch_halo(cur, 0, ab, aa)
+                hb, ha, pending = self._start_fetch_halo(cur, 0, ab, aa, hb_dst, ha_dst)
                 self.engine.analysis_run(cur, hb, ha, outs, ab, n - aa, s)
                 self._finish_exchange(pending)
-                if cur_buf is not None:
+                if cur_buf is not None and hasattr(self.engine, "analysis_ends"):
                     self.engine.analysis_ends(cur_buf, outs, s)           # both ends, one launch
                 else:
                     if ab:
                         self.engine.analysis_run(cur, hb, ha, outs, 0, ab, s)
                     self.engine.analysis_run(cur, hb, ha, outs, n - aa, n, s)
             else:
-                hb, ha = self._fetch_halo(cur, 0, ab, aa)
-                if hasattr(self.engine, "analysis_split") and getattr(self.engine, "supports_split",
-                                                                      getattr(self.engine, "supports_scatter", False)):
-                    self.engine.analysis_split(cur, hb, ha, outs, s)
+                hb, ha, pending = self._start_fetch_halo(cur, 0, ab, aa, hb_dst, ha_dst)
+                self._finish_exchange(pending)
+                if cur_buf is not None:
+                    self.engine.analysis(cur_buf, outs, s)
                 else:
-                    self.engine.analysis(torch.cat([hb, cur, ha], 0), outs, s)
+                    self.engine.analysis_split(cur, hb, ha, outs, s)
             cur, cur_buf = a_out, a_buf
         return y
 
@@ -341,20 +369,26 @@ class ShardedNdDwt:
                         self.engine.synthesis_part(ins, 0, part_b, s)
                     self.engine.synthesis_part(ins, sa + n, part_a, s)
                 pending = self._start_scatter(part_b, part_a, sa, sb)
-                own = prev.new_empty((n,) + inner)
+                own = prev.new_empty((n,) + inner) if lev == 1 else self._buf(("syn_own", lev & 1), (n,) + inner, prev)
                 self.engine.synthesis_part(ins, sa, own, s)
                 self._finish_scatter(pending, own)
                 prev = own
             elif self.scheme == "scatter":
                 # zero-extended synthesis: partial sums for sa planes before and sb planes after the slab
-                ext = prev.new_empty((sa + self.n_local + sb,) + tuple(prev.shape[1:]))
+                ext_shape = (sa + self.n_local + sb,) + tuple(prev.shape[1:])
+                ext = prev.new_empty(ext_shape) if lev == 1 else self._buf(("syn_ext", lev & 1), ext_shape, prev)
                 self.engine.synthesis_ext(ins, ext, s)
                 prev = self._scatter_add(ext, sa, sb)
             else:
-                stack = torch.stack(ins, 0)
-                hb, ha = self._fetch_halo(stack, 1, sb, sa)
-                full = torch.cat([hb, stack, ha], 1)
-                out = torch.empty_like(prev)
+                # gather scheme (engines without the zero-extended synthesis: per-axis kernels, dilated levels): the 2^d bands
+                # are assembled with their halo planes in one scratch array, the halos received in place
+                n = self.n_local
+                full = self._buf(("syn_full",), (nb, sb + n + sa) + tuple(prev.shape[1:]), prev)
+                for b in range(nb):
+                    full[b, sb:sb + n].copy_(ins[b])
+                hb, ha, pending = self._start_fetch_halo(full[:, sb:sb + n], 1, sb, sa, full[:, :sb], full[:, sb + n:])
+                self._finish_exchange(pending)
+                out = torch.empty_like(prev) if lev == 1 else self._buf(("syn_out", lev & 1), prev.shape, prev)
                 self.engine.synthesis([full[b] for b in range(nb)], out, s)
                 prev = out
         return prev.contiguous()

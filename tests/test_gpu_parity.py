@@ -582,6 +582,64 @@ def _t_sharded_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _thin_slab_worker(rank, world, port, q):
+    """cfg5's regime on the product engine: slabs THINNER than the filter (4 planes per rank, db4 = 8 taps: halo 3 + 4 >= slab, so
+    the exchange is multi-hop and the plans are slab plans), 4-D sharded on t and 3-D sharded on z; and the a-trous dilation
+    through the gather scheme of the HIP engine"""
+    import importlib
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sh = importlib.import_module("non-decimated_wavelets_amd.sharded")
+        dev = torch.device("cuda", 0)
+        errs = []
+        for sizes, wn, level, dilation in (([24, 20, 12, 16], "db4", 2, "reference"),       # 4-D, t = 16 over 4 ranks
+                                            ([40, 24, 16], "db4", 3, "reference"),           # 3-D, z = 16 over 4 ranks
+                                            ([24, 20, 16], "db2", 2, "atrous"),              # dilated taps: gather scheme, per-axis kernels
+                                            ([40, 24, 18], "db6", 2, "reference")):          # uneven 4/5/4/5 planes, 12 taps
+            d = len(sizes)
+            torch.manual_seed(21)
+            xs = torch.randn(*reversed(sizes), device=dev)
+            w = _cls(d)(wn, sizes, "pres_l2_norm", 1, "precision", "single", "dilation", dilation)
+            perm = tuple(reversed(range(d)))
+            yref = w.dec(xs.permute(*perm), level).permute(*reversed(range(d + 1)))
+            eng = sh.ShardedNdDwt([wn] * d, sizes, pres_l2_norm=True, precision="single", dilation=dilation, device=dev)
+            assert eng.n_local < len(ndwt.wave_filters(wn)[0]) or dilation == "atrous" or wn == "db6"
+            yl = eng.dec(xs[eng.z0:eng.z1].contiguous(), level)
+            e_dec = float((yl - yref[:, eng.z0:eng.z1]).abs().max() / yref.abs().max())
+            e_rec = float((eng.rec(yl) - xs[eng.z0:eng.z1]).abs().max())
+            yl2 = eng.dec(xs[eng.z0:eng.z1].contiguous(), level)           # second call: the cached scratch buffers are reused
+            e_again = float((yl2 - yl).abs().max())
+            errs.append((max(e_dec, e_again), e_rec))
+        q.put((rank, errs))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_thin_slabs_and_atrous_on_the_hip_engine_over_gloo():
+    for rank, errs in _run_ranks(_thin_slab_worker, 4):
+        for e_a, e_b in errs:
+            assert e_a <= 4e-6 and e_b <= 2e-5, (rank, errs)
+
+
+def test_slab_plan_checks_the_whole_axis_not_the_slab():
+    """ndwt_plan_create_slab: the reference's filter-length check (nd_dwt_3D.m:277-286) applies to the sharded axis of the whole
+    volume; a thin slab plan serves the slab entry points only"""
+    api = __import__("importlib").import_module("non-decimated_wavelets_amd.api")
+    with pytest.raises(ndwt.NdwtError, match="Fourth Dimension of Data is shorter"):
+        api.Plan([32, 32, 16, 4], ["db4"] * 4, torch.float32)
+    p = api.Plan([32, 32, 16, 4], ["db4"] * 4, torch.float32, global_outer=32)
+    assert p.slab_halo(1) == (3, 4, 4, 3)
+    with pytest.raises(ndwt.NdwtError, match="slab"):
+        p.dec(1, 1, 1)
+    with pytest.raises(ndwt.NdwtError, match="Fourth Dimension of Data is shorter"):
+        api.Plan([32, 32, 16, 4], ["db4"] * 4, torch.float32, global_outer=6)
+    with pytest.raises(ndwt.NdwtError, match="global_outer"):
+        api.Plan([32, 32, 16, 4], ["db4"] * 4, torch.float32, global_outer=3)
+
+
 def _run_ranks(worker, world):
     import socket
     import torch.multiprocessing as mp
