@@ -12,8 +12,11 @@
  * Complex data: with the interleaved-complex mex API (mex -R2018a, MX_HAS_INTERLEAVED_COMPLEX) the array goes through
  * an NDWT_COMPLEX_INTERLEAVED plan; with the split API of the reference's gateway (mxGetPr / mxGetPi,
  * nd_dwt_mex.c:55-58) the real and imaginary parts go through ndwt_{dec,rec}_split_host on a real plan.
- * Build:  matlab/ndwt_hip_compile.m.
- * NOT compiled in the build container (no MATLAB / mex.h there); all behaviour is tested through the C ABI.
+ *
+ * Plans are cached across calls (iterative solvers call dec / rec with one configuration thousands of times; a plan owns two
+ * scratch volumes on the device) and released by mexAtExit -- the reference re-plans FFTW on every call (nddwt.c:110-111).
+ * Build: matlab/ndwt_hip_compile.m.  No MATLAB in the build container: tests/test_abi.py checks this file's syntax against
+ * declarations-only stand-ins of mex.h / matrix.h; behaviour is tested through the C ABI it calls.
  */
 #include <string.h>
 
@@ -21,19 +24,99 @@
 #include "matrix.h"
 #include "ndwt.h"
 
-static void fail(const char* what) {
-    /* the reference raises this identifier for every gateway error (nd_dwt_mex.c:20,24,28,37,42,49,125) */
-    mexErrMsgIdAndTxt("MATLAB:FFT2mx:invalidNumInputs", "%s: %s", what, ndwt_last_error());
+#define ERR_ID "MATLAB:FFT2mx:invalidNumInputs" /* the identifier of every reference gateway error (nd_dwt_mex.c:20,...,125) */
+#define NCACHE 8
+
+typedef struct {
+    ndwt_plan* plan;
+    int ndim, dtype, cplx, l2, dilation, max_level;
+    int64_t dims[NDWT_MAX_DIMS];
+    char names[NDWT_MAX_DIMS][16];
+    unsigned long stamp; /* last use, for eviction */
+} cached_plan;
+
+static cached_plan g_cache[NCACHE];
+static unsigned long g_clock = 0;
+static int g_at_exit = 0;
+
+static void release_plans(void) {
+    int i;
+    for (i = 0; i < NCACHE; ++i) {
+        if (g_cache[i].plan) ndwt_plan_destroy(g_cache[i].plan);
+        g_cache[i].plan = NULL;
+    }
+}
+
+static void fail(const char* what) { mexErrMsgIdAndTxt(ERR_ID, "%s: %s", what, ndwt_last_error()); }
+
+/* the cached plan of this configuration (created, or re-created with more levels, when needed) */
+static ndwt_plan* get_plan(int ndim, const int64_t* dims, char names[][16], int dtype, int cplx, int l2, int dilation, int level) {
+    int i, a, victim = 0;
+    const char* wn[NDWT_MAX_DIMS];
+    if (!g_at_exit) {
+        mexAtExit(release_plans);
+        g_at_exit = 1;
+    }
+    for (i = 0; i < NCACHE; ++i) {
+        cached_plan* c = &g_cache[i];
+        int same = c->plan && c->ndim == ndim && c->dtype == dtype && c->cplx == cplx && c->l2 == l2 && c->dilation == dilation;
+        for (a = 0; same && a < ndim; ++a) same = c->dims[a] == dims[a] && !strcmp(c->names[a], names[a]);
+        if (same && c->max_level >= level) {
+            c->stamp = ++g_clock;
+            return c->plan;
+        }
+        if (same) { /* same transform, deeper than planned for: rebuild in place */
+            victim = i;
+            goto build;
+        }
+    }
+    victim = -1;
+    for (i = 0; i < NCACHE && victim < 0; ++i) /* an empty slot ... */
+        if (!g_cache[i].plan) victim = i;
+    if (victim < 0) {                          /* ... else the least recently used */
+        victim = 0;
+        for (i = 1; i < NCACHE; ++i)
+            if (g_cache[i].stamp < g_cache[victim].stamp) victim = i;
+    }
+build:
+    if (g_cache[victim].plan) ndwt_plan_destroy(g_cache[victim].plan);
+    g_cache[victim].plan = NULL;
+    for (a = 0; a < ndim; ++a) wn[a] = names[a];
+    if (ndwt_plan_create(&g_cache[victim].plan, ndim, dims, wn, dtype, cplx, l2, dilation, level < 3 ? 3 : level, 0) != NDWT_OK) {
+        g_cache[victim].plan = NULL;
+        fail("plan");
+    }
+    g_cache[victim].ndim = ndim;
+    g_cache[victim].dtype = dtype;
+    g_cache[victim].cplx = cplx;
+    g_cache[victim].l2 = l2;
+    g_cache[victim].dilation = dilation;
+    g_cache[victim].max_level = level < 3 ? 3 : level;
+    for (a = 0; a < ndim; ++a) {
+        g_cache[victim].dims[a] = dims[a];
+        strcpy(g_cache[victim].names[a], names[a]);
+    }
+    g_cache[victim].stamp = ++g_clock;
+    return g_cache[victim].plan;
 }
 
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
-    if (nrhs < 5) mexErrMsgIdAndTxt("MATLAB:FFT2mx:invalidNumInputs", "Five Inputs Required");
-    const mxArray* x = prhs[0];
-    if (!mxIsDouble(x) && !mxIsSingle(x)) mexErrMsgIdAndTxt("MATLAB:FFT2mx:invalidNumInputs", "Arrays must be double or single");
-    const int inverse = mxGetScalar(prhs[2]) != 0;
-    const int level = (int)mxGetScalar(prhs[3]);
-    const int l2 = mxGetScalar(prhs[4]) != 0;
-    int dilation = NDWT_DILATION_REFERENCE;
+    const mxArray* x;
+    const mwSize* d;
+    mwSize nd, od[NDWT_MAX_DIMS + 1], ond;
+    int inverse, level, l2, dilation = NDWT_DILATION_REFERENCE, ndim, a, dtype, cplx, rc;
+    int64_t dims[NDWT_MAX_DIMS];
+    char names[NDWT_MAX_DIMS][16];
+    ndwt_plan* plan;
+
+    if (nrhs < 5) mexErrMsgIdAndTxt(ERR_ID, "Five Inputs Required");             /* nd_dwt_mex.c:19-21 */
+    if (nlhs > 1) mexErrMsgIdAndTxt(ERR_ID, "Too many output arguments.");        /* :23-25 */
+    x = prhs[0];
+    if (!mxIsDouble(x) && !mxIsSingle(x)) mexErrMsgIdAndTxt(ERR_ID, "Arrays must be double or single");
+    inverse = mxGetScalar(prhs[2]) != 0;
+    level = (int)mxGetScalar(prhs[3]);
+    l2 = mxGetScalar(prhs[4]) != 0;
+    if (level < 1) mexErrMsgIdAndTxt(ERR_ID, "level must be at least 1");
     if (nrhs > 5) {
         char buf[16];
         mxGetString(prhs[5], buf, sizeof buf);
@@ -41,51 +124,56 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     }
 
     /* dims: column vectors are 1-D like nd_dwt_mex.c:68-70; the inverse input carries the band axis last (:115) */
-    mwSize nd = mxGetNumberOfDimensions(x);
-    const mwSize* d = mxGetDimensions(x);
-    int ndim = (int)nd - (inverse ? 1 : 0);
+    nd = mxGetNumberOfDimensions(x);
+    d = mxGetDimensions(x);
+    ndim = (int)nd - (inverse ? 1 : 0);
     if (!inverse && nd == 2 && d[1] == 1) ndim = 1;
     if (inverse && nd == 2) ndim = 1;
-    if (ndim < 1 || ndim > NDWT_MAX_DIMS) mexErrMsgIdAndTxt("MATLAB:FFT2mx:invalidNumInputs", "1 to 4 dimensions supported");
-    int64_t dims[NDWT_MAX_DIMS];
-    for (int a = 0; a < ndim; ++a) dims[a] = (int64_t)d[a];
-
-    /* wavelet names */
-    char names[NDWT_MAX_DIMS][16];
-    const char* wn[NDWT_MAX_DIMS];
-    for (int a = 0; a < ndim; ++a) {
-        if (mxIsCell(prhs[1])) mxGetString(mxGetCell(prhs[1], a < (int)mxGetNumberOfElements(prhs[1]) ? a : 0), names[a], 16);
-        else mxGetString(prhs[1], names[a], 16);
-        wn[a] = names[a];
+    if (ndim < 1 || ndim > NDWT_MAX_DIMS) mexErrMsgIdAndTxt(ERR_ID, "1 to 4 dimensions supported");
+    for (a = 0; a < ndim; ++a) dims[a] = (int64_t)d[a];
+    /* the size-consistency guard of nd_dwt_mex.c:124-127: the band axis of an inverse input must hold exactly the bands of
+     * `level` levels -- ndwt_rec_host reads prod(dims) * bands elements from it */
+    if (inverse) {
+        const int64_t have = (int)nd > ndim ? (int64_t)d[ndim] : 1;
+        if (have != ndwt_num_bands(ndim, level)) mexErrMsgIdAndTxt(ERR_ID, "FIlter size and image size not consistant");
     }
 
-    const int dtype = mxIsSingle(x) ? NDWT_F32 : NDWT_F64;
+    /* wavelet names: one per axis, or one for all */
+    for (a = 0; a < ndim; ++a) {
+        if (mxIsCell(prhs[1])) {
+            const int ncell = (int)mxGetNumberOfElements(prhs[1]);
+            if (ncell != ndim && ncell != 1) mexErrMsgIdAndTxt(ERR_ID, "one wavelet name per dimension, or a single name");
+            if (mxGetString(mxGetCell(prhs[1], ncell == 1 ? 0 : a), names[a], 16)) mexErrMsgIdAndTxt(ERR_ID, "bad wavelet name");
+        } else if (mxGetString(prhs[1], names[a], 16)) {
+            mexErrMsgIdAndTxt(ERR_ID, "bad wavelet name");
+        }
+    }
+
+    dtype = mxIsSingle(x) ? NDWT_F32 : NDWT_F64;
 #if MX_HAS_INTERLEAVED_COMPLEX
-    const int cplx = mxIsComplex(x) ? NDWT_COMPLEX_INTERLEAVED : NDWT_REAL;
+    cplx = mxIsComplex(x) ? NDWT_COMPLEX_INTERLEAVED : NDWT_REAL;
 #else
-    const int cplx = NDWT_REAL;                          /* split storage: one real transform per part */
+    cplx = NDWT_REAL;                                    /* split storage: one real transform per part */
 #endif
-    ndwt_plan* plan = NULL;
-    if (ndwt_plan_create(&plan, ndim, dims, wn, dtype, cplx, l2, dilation, level, 0) != NDWT_OK) fail("plan");
+    plan = get_plan(ndim, dims, names, dtype, cplx, l2, dilation, level);
 
     /* output: MATLAB-owned, like mxCreateNumericArray at nd_dwt_mex.c:86,136 */
-    mwSize od[NDWT_MAX_DIMS + 1];
-    for (int a = 0; a < ndim; ++a) od[a] = (mwSize)dims[a];
-    mwSize ond = (mwSize)ndim;
+    for (a = 0; a < ndim; ++a) od[a] = (mwSize)dims[a];
+    ond = (mwSize)ndim;
     if (!inverse) od[ond++] = (mwSize)ndwt_num_bands(ndim, level);
     if (ond == 1) od[ond++] = 1;
     plhs[0] = mxCreateNumericArray(ond, od, mxIsSingle(x) ? mxSINGLE_CLASS : mxDOUBLE_CLASS, mxIsComplex(x) ? mxCOMPLEX : mxREAL);
 
 #if MX_HAS_INTERLEAVED_COMPLEX
-    int rc = inverse ? ndwt_rec_host(plan, mxGetData(x), mxGetData(plhs[0]), level)
-                     : ndwt_dec_host(plan, mxGetData(x), mxGetData(plhs[0]), level);
+    rc = inverse ? ndwt_rec_host(plan, mxGetData(x), mxGetData(plhs[0]), level)
+                 : ndwt_dec_host(plan, mxGetData(x), mxGetData(plhs[0]), level);
 #else
-    const void* x_im = mxIsComplex(x) ? mxGetImagData(x) : NULL;
-    void* y_im = mxIsComplex(x) ? mxGetImagData(plhs[0]) : NULL;
-    int rc = inverse ? ndwt_rec_split_host(plan, mxGetData(x), x_im, mxGetData(plhs[0]), y_im, level)
+    {
+        const void* x_im = mxIsComplex(x) ? mxGetImagData(x) : NULL;
+        void* y_im = mxIsComplex(x) ? mxGetImagData(plhs[0]) : NULL;
+        rc = inverse ? ndwt_rec_split_host(plan, mxGetData(x), x_im, mxGetData(plhs[0]), y_im, level)
                      : ndwt_dec_split_host(plan, mxGetData(x), x_im, mxGetData(plhs[0]), y_im, level);
+    }
 #endif
-    ndwt_plan_destroy(plan);
     if (rc != NDWT_OK) fail(inverse ? "rec" : "dec");
-    (void)nlhs;
 }

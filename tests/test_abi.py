@@ -98,3 +98,20 @@ def test_host_classes_validate_like_the_reference():
     assert w.pres_l2_norm == 0 and w.f_size == {"s1": 4} and w.sizes == [4096]
     w = ndwt.nd_dwt_4D("db2", [8, 8, 8, 8], pres_l2_norm=1, precision="single")
     assert w.wname == ["db2"] * 4 and w.pres_l2_norm == 1 and w._level_from_bands(46) == 3
+
+
+def test_mex_shim_syntax_against_declaration_stubs():
+    """matlab/nd_dwt_hip_mex.c cannot be built here (no MATLAB): the compiler at least checks its syntax and the types it passes
+    to the C ABI, against declarations-only stand-ins of mex.h / matrix.h (tests/stubs/), for both complex-storage APIs.
+    Syntax only: nothing is linked or run, and no behaviour is pinned by this."""
+    import shutil
+    import subprocess
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ([], ["-DMX_HAS_INTERLEAVED_COMPLEX=1"]):
+        r = subprocess.run([cc, "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-std=c99", "-I", os.path.join(root, "tests", "stubs"),
+                            "-I", os.path.join(root, "include")] + extra + [os.path.join(root, "matlab", "nd_dwt_hip_mex.c")],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
