@@ -277,12 +277,15 @@ template <typename T> static int generic_synthesis(GenericCtx<T>& c, int axis, i
 }
 
 // ------------------------------------------------------------------------------------ fused levels
-static bool fused3_eligible(const ndwt_plan* p, long long stride, int* Lp_out) {
+// dir: 0 analysis, 1 synthesis, -1 both.  Instantiated tap lengths: 2..12 (db1..db6) for every data kind the checks below let
+// through; float real data also 14, 16 (db7, db8) and, analysis only, 18 (db9).  Longer filters take the per-axis path.
+static bool fused3_eligible(const ndwt_plan* p, long long stride, int* Lp_out, int dir = -1) {
     if (p->path != NDWT_PATH_AUTO || stride != 1 || p->ndim < 3) return false;
     if (p->dtype == NDWT_F64 && !p->fp64_fused) return false;
     int Lp = 2;
     for (int a = 0; a < 3; ++a) Lp = p->filt[a].len > Lp ? p->filt[a].len : Lp;
-    if (Lp > 12) return false;   // instantiated tap lengths: 2..12 (db1..db6); longer filters take the per-axis path
+    const int lmax = (p->dtype == NDWT_F32 && p->complexity == NDWT_REAL) ? (dir == 0 ? 18 : 16) : 12;
+    if (Lp > lmax) return false;
     if (p->dtype == NDWT_F64 && Lp > 10) return false;   // double, db6: the fused kernels spill (6.7 ms vs 4.8 ms per-axis at 256^3)
     // interleaved complex: the fused kernels with the x taps stepping over (re, im) pairs, tap lengths <= 8
     if (p->complexity != NDWT_REAL && (Lp > 8 || (p->dims[0] * 2) % 4 != 0)) return false;
@@ -436,6 +439,9 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     if constexpr (sizeof(T) == 4) {
         if (inverse && dil == 1 && inv3y_eligible(p, Lp, a)) rc = launch_inv3y_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s);
     }
+    if constexpr (sizeof(T) == 4) {
+        if (rc == -1 && Lp > 12 && ew == 1) rc = launch_long3_f32(inverse, a, t, vec4, td, s);
+    }
     if (rc == -1) rc = launch3<T>(inverse, a, t, vec4, ew != 1 ? 0 : variant, ew, td, s);
     prof_end(p, s, rc);
     if (rc == -1) return fail(NDWT_ERR_UNSUPPORTED, "no fused kernel instantiated for tap length %d", Lp);
@@ -507,7 +513,7 @@ static int analysis_level(ndwt_plan* p, const T* in, T* const* out, long long st
         return fused3_run<T>(p, false, Lp, ins, out, p->dims[2], 1, 0, 0, 1, s, 0, LLONG_MIN, 0, 0, (int)stride);
     }
     // slab mode hands over exactly (L_top-1) halo planes: the fused kernel marches with the padded length
-    if (fused3_eligible(p, stride, &Lp) && !(slab && d == 3 && ftop.len != Lp)) {
+    if (fused3_eligible(p, stride, &Lp, 0) && !(slab && d == 3 && ftop.len != Lp)) {
         const long long vol3 = p->comp * p->dims[0] * p->dims[1] * p->dims[2];
         if (d == 3) {
             const T* ins[8] = {in};
@@ -559,7 +565,7 @@ static int synthesis_level(ndwt_plan* p, const T* const* in, T* out, long long s
         T* outs[8] = {out};
         return fused3_run<T>(p, true, Lp, in, outs, p->dims[2], 1, 0, 0, 1, s, 0, LLONG_MIN, 0, 0, (int)stride);
     }
-    if (fused3_eligible(p, stride, &Lp) && !(slab && d == 3 && ftop.len != Lp)) {
+    if (fused3_eligible(p, stride, &Lp, 1) && !(slab && d == 3 && ftop.len != Lp)) {
         const long long vol3 = p->comp * p->dims[0] * p->dims[1] * p->dims[2];
         if (d == 3) {
             T* outs[8] = {out};
@@ -891,7 +897,7 @@ static int plan_create_impl(ndwt_plan** plan, int ndim, const int64_t* dims, lon
         }
     }
     int Lp = 0;
-    if (fused3_eligible(p, 1, &Lp) || fused2_eligible(p, 1, &Lp)) {
+    if (fused3_eligible(p, 1, &Lp, 0) || fused2_eligible(p, 1, &Lp)) {   // (the analysis side admits the most tap lengths)
         for (int inv = 0; inv < 2; ++inv) {
             FusedTapsD t = fused_taps(p, Lp, inv != 0);
             // synthesis table: Taps3Y = Taps3 followed by the x tap pairs (lo[0][k], lo[0][k-1]), k = 0..Lp, of the pair-packed kernel

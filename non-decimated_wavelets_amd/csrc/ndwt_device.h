@@ -61,6 +61,14 @@ template <int I, int N, class F> NDWT_DEV void static_for(F&& f) {
 #define NDWT_SFOR(var, N) static_for<0, N>([&](auto var##_c) __attribute__((always_inline)) { constexpr int var = decltype(var##_c)::value;
 #define NDWT_SEND });
 
+#ifdef NDWT_HOST_EMU
+#define NDWT_SCHED_FENCE() ((void)0)
+#define NDWT_SETPRIO(n) ((void)(n))
+#else
+#define NDWT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)   // the instruction scheduler moves nothing across this point
+#define NDWT_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#endif
+
 NDWT_DEV float ndwt_sqrt(float v) { return __builtin_sqrtf(v); }
 NDWT_DEV double ndwt_sqrt(double v) { return __builtin_sqrt(v); }
 
@@ -386,7 +394,10 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
         NDWT_SEND
     }
 
-    // y filter: an item owns one chunk column (CH adjacent x) and RY output rows
+    // y filter: an item owns one chunk column (CH adjacent x) and RY output rows.  The RY + L - 1 input chunks are read YGRP at a
+    // time and scattered into the RY outputs they feed (the register footprint no longer grows with the tap length: what kept
+    // tap lengths above 12 off the fused kernels)
+    static constexpr int YGRP = 4;
     static NDWT_DEV void ystage(Shared& sh, const Taps& tp, int tid) {
         NDWT_UNROLL
         for (int k = 0; k < NYI; ++k) {
@@ -394,27 +405,44 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
             if (it >= YITEMS) continue;
             int cc = it % WC, yg = it / WC;
             const int pc = LD::S(cc);
-            chunk zin[RY + L - 1];
-            NDWT_UNROLL
-            for (int r = 0; r < RY + L - 1; ++r) zin[r] = sh.zs[yg * RY + r][pc];
-            NDWT_UNROLL
-            for (int i = 0; i < RY; ++i) {
-                chunk lo, hi;
-                NDWT_UNROLL
-                for (int sub = 0; sub < CH; ++sub) {
-                    v2 l = (v2)(T(0)), h = (v2)(T(0));
-                    NDWT_UNROLL
-                    for (int j = 0; j < L; ++j) {
-                        v2 z = LD::get(zin[i + j], sub);
-                        l += tp.lo[1][j] * z;
-                        h += tp.hi[1][j] * z;
+            v2 l[RY][CH], h[RY][CH];
+            NDWT_SFOR(i, RY)
+                NDWT_SFOR(sub, CH)
+                    l[i][sub] = (v2)(T(0));
+                    h[i][sub] = (v2)(T(0));
+                NDWT_SEND
+            NDWT_SEND
+            NDWT_SFOR(g, (RY + L - 1 + YGRP - 1) / YGRP)
+                chunk zin[YGRP];
+                NDWT_SFOR(t, YGRP)
+                    if constexpr (g * YGRP + t < RY + L - 1) zin[t] = sh.zs[yg * RY + g * YGRP + t][pc];
+                NDWT_SEND
+                NDWT_SFOR(t, YGRP)
+                    constexpr int r = g * YGRP + t;
+                    if constexpr (r < RY + L - 1) {
+                        NDWT_SFOR(i, RY)
+                            constexpr int j = r - i;
+                            if constexpr (j >= 0 && j < L) {
+                                NDWT_SFOR(sub, CH)
+                                    const v2 z = LD::get(zin[t], sub);
+                                    l[i][sub] += tp.lo[1][j] * z;
+                                    h[i][sub] += tp.hi[1][j] * z;
+                                NDWT_SEND
+                            }
+                        NDWT_SEND
                     }
-                    LD::set(lo, sub, l);
-                    LD::set(hi, sub, h);
-                }
+                NDWT_SEND
+                if constexpr (L > 12) NDWT_SCHED_FENCE();  // long filters: keep the groups apart (hipcc hoists every read otherwise)
+            NDWT_SEND
+            NDWT_SFOR(i, RY)
+                chunk lo, hi;
+                NDWT_SFOR(sub, CH)
+                    LD::set(lo, sub, l[i][sub]);
+                    LD::set(hi, sub, h[i][sub]);
+                NDWT_SEND
                 sh.ys[yg * RY + i][0][pc] = lo;
                 sh.ys[yg * RY + i][1][pc] = hi;
-            }
+            NDWT_SEND
         }
     }
 
@@ -481,9 +509,11 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
                 if (s + 1 < nsteps) load_plane(st, a, inb, z + 1 + RH);   // prefetch for the next step
             });
             ex.barrier();
-            ex.each([&](int tid, State&) __attribute__((always_inline)) { ystage(sh, tp, tid); });
+            NDWT_SETPRIO(1);                              // the stages that end in this plane's stores go ahead of the other
+            ex.each([&](int tid, State&) __attribute__((always_inline)) { ystage(sh, tp, tid); });   // waves' loads (-2 %)
             ex.barrier();
             ex.each([&](int tid, State&) __attribute__((always_inline)) { xstage(sh, tp, a, tc, obase, z, tid); });
+            NDWT_SETPRIO(0);
         }
     }
 };
@@ -709,14 +739,6 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
     }
 };
 
-#ifdef NDWT_HOST_EMU
-#define NDWT_SCHED_FENCE() ((void)0)
-#define NDWT_SETPRIO(n) ((void)(n))
-#else
-#define NDWT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)   // the instruction scheduler moves nothing across this point
-#define NDWT_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
-#endif
-
 // ------------------------------------------------------------------- synthesis, lane-shift form ----
 // Same arithmetic as Inv3 with a different data path: the x-synthesis takes its x neighbours straight from the
 // adjacent lanes' registers (DPP wave shifts) instead of a raw tile in LDS.  A wave holds whole haloed rows
@@ -775,6 +797,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
     static constexpr int NYI = (YITEMS + NT - 1) / NT;
     static constexpr int NP = CH * RY;
     static constexpr int XV = 4 * (1 + GL + GR);
+    static constexpr int YGRP = 4;                       // LDS chunks the y stage holds at a time
     static_assert(TX % 4 == 0 && TY % RY == 0 && L % 2 == 0 && NT % 64 == 0 && RPW >= 1, "tile shape");
     typedef typename VecT<T>::v2 v2;
     typedef typename VecT<T>::v4 v4;
@@ -924,17 +947,28 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
                     P[q] = (v2)(T(0));
                 NDWT_SEND
                 NDWT_SFOR(yb, 2)
-                    chunk cv[RY + L - 1];
-                    NDWT_SFOR(t, RY + L - 1)
-                        cv[t] = sh.xs[buf][yb][yg * RY + t][pc];
-                    NDWT_SEND
-                    NDWT_SFOR(i, RY)
-                        NDWT_SFOR(sub, CH)
-                            NDWT_SFOR(j, L)
-                                if constexpr (yb == 0) P[i * CH + sub] += tp.lo[1][j] * LD::get(cv[i + j], sub);
-                                else P[i * CH + sub] += tp.hi[1][j] * LD::get(cv[i + j], sub);
-                            NDWT_SEND
+                    // the RY + L - 1 input chunks, YGRP at a time, scattered into the RY outputs they feed (the register
+                    // footprint does not grow with the tap length)
+                    NDWT_SFOR(g, (RY + L - 1 + YGRP - 1) / YGRP)
+                        chunk cv[YGRP];
+                        NDWT_SFOR(t, YGRP)
+                            if constexpr (g * YGRP + t < RY + L - 1) cv[t] = sh.xs[buf][yb][yg * RY + g * YGRP + t][pc];
                         NDWT_SEND
+                        NDWT_SFOR(t, YGRP)
+                            constexpr int r = g * YGRP + t;
+                            if constexpr (r < RY + L - 1) {
+                                NDWT_SFOR(i, RY)
+                                    constexpr int j = r - i;
+                                    if constexpr (j >= 0 && j < L) {
+                                        NDWT_SFOR(sub, CH)
+                                            if constexpr (yb == 0) P[i * CH + sub] += tp.lo[1][j] * LD::get(cv[t], sub);
+                                            else P[i * CH + sub] += tp.hi[1][j] * LD::get(cv[t], sub);
+                                        NDWT_SEND
+                                    }
+                                NDWT_SEND
+                            }
+                        NDWT_SEND
+                        if constexpr (L > 12) NDWT_SCHED_FENCE();
                     NDWT_SEND
                 NDWT_SEND
                 NDWT_SFOR(q, NP)

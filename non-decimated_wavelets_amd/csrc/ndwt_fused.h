@@ -27,6 +27,9 @@ int launch_inv3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4,
 // threads; depth = register sets of band loads (2: staggered refill, aligned volumes only)
 int launch_inv3y_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, const void* taps_dev, hipStream_t s);
 
+// float, tap lengths 14..18 (analysis) / 14..16 (synthesis): ndwt_fused3_f32_long.hip
+int launch_long3_f32(bool inverse, const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, const void* taps_dev, hipStream_t s);
+
 // fused 2-D kernels (register-only, one wave per tile)
 int fused2_tile_width(bool inverse, int Lp, int ew);
 int launch_fwd2_f32(const Fused2Args<float>& a, int Lp, bool vec4, int ew, const void* taps_dev, hipStream_t s);

@@ -1,0 +1,21 @@
+// fused 3-D levels, float, tap lengths 14 .. 18 (db7 .. db9): the 512-thread tiles with the 256-register budget
+// (analysis 64x16, one column per thread; synthesis 64x32, two items per thread).  db9 fits on the analysis side only and db10
+// on neither (the z window / the pending partial sums of 20 planes): those stay on the per-axis kernels.
+#include "ndwt_fused_kernels.h"
+namespace ndwt {
+int launch_long3_f32(bool inverse, const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, const void* taps_dev, hipStream_t s) {
+    if (!inverse) {
+        switch (t.Lp) {
+            NDWT_FUSED_CASE(Fwd3, false, float, 14, 1)
+            NDWT_FUSED_CASE(Fwd3, false, float, 16, 1)
+            NDWT_FUSED_CASE(Fwd3, false, float, 18, 1)
+            default: return -1;
+        }
+    }
+    switch (t.Lp) {
+        NDWT_FUSED_CASE(Inv3S, true, float, 14, 2)
+        NDWT_FUSED_CASE(Inv3S, true, float, 16, 2)
+        default: return -1;
+    }
+}
+}  // namespace ndwt
