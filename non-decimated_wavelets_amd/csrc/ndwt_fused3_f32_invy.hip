@@ -9,18 +9,23 @@ template <int LL, bool V, int DEPTH> static int go(const Fused3Args<float>& a, c
     return launch_fused3<K>(a, unused, taps_dev, s);
 }
 
-// depth 2 (two register sets of band loads, staggered refill) is the default; depth 1 serves unaligned volumes and A/B runs
-#define NDWT_INVY_CASE(LL) \
-    case LL:               \
-        return vec4 ? (depth == 2 ? go<LL, true, 2>(a, taps_dev, s) : go<LL, true, 1>(a, taps_dev, s)) : go<LL, false, 1>(a, taps_dev, s);
+// depth 2 (two register sets of band loads, staggered refill) is the default where it fits the 128 registers of a 1024-thread
+// workgroup without spills (tap lengths 2 and 8; 4 and 6 spill a few registers, and a spill reload in the plane loop waits
+// vmcnt(0), i.e. for every load in flight); depth 1 serves the others, unaligned volumes and A/B runs
+#define NDWT_INVY_CASE(LL, D2OK) \
+    case LL:                     \
+        if constexpr (D2OK) {    \
+            if (vec4 && depth == 2) return go<LL, true, 2>(a, taps_dev, s); \
+        }                        \
+        return vec4 ? go<LL, true, 1>(a, taps_dev, s) : go<LL, false, 1>(a, taps_dev, s);
 
 int launch_inv3y_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, const void* taps_dev, hipStream_t s) {
     switch (Lp) {
-        NDWT_INVY_CASE(8)
+        NDWT_INVY_CASE(8, true)
 #ifndef NDWT_INVY_DB4_ONLY
-        NDWT_INVY_CASE(2)
-        NDWT_INVY_CASE(4)
-        NDWT_INVY_CASE(6)
+        NDWT_INVY_CASE(2, true)
+        NDWT_INVY_CASE(4, false)
+        NDWT_INVY_CASE(6, false)
 #endif
         default: return -1;
     }
