@@ -170,6 +170,23 @@ int ndwt_analysis_level_slab_runs(ndwt_plan* plan, const void* in_with_halo, voi
 int ndwt_synthesis_level_slab_runs(ndwt_plan* plan, const void* const* in_local, int64_t n_in, int64_t e0, int64_t e_stride,
                                    int64_t n_runs, int64_t n_out, void* out, int stride, void* stream);
 
+/* ---- single-process multi-device plan (hard part 5; section 8b `devices[]`) ---------------------------
+ * The reference's host is ONE process calling one gateway (nd_dwt_3D.m:161,225): this is the multi-GPU path that fits behind
+ * that call.  The volume is sharded in slabs on its outermost axis over devices[0..ndev) (a device may appear more than once:
+ * independent slabs and streams on one GPU); one host thread drives all of them, halo planes move between slabs with
+ * asynchronous device-to-device (peer, xGMI) copies ordered by events.  Host arrays in and out, whole volume, the layout of
+ * ndwt_dec_host / ndwt_rec_host; results equal the single-device transform bit for bit (gather exchange in both directions).
+ * ndim 2..4.  Errors: ndwt_mplan_last_error(). */
+typedef struct ndwt_mplan ndwt_mplan;
+int ndwt_mplan_create(ndwt_mplan** plan, int ndim, const int64_t* dims, const char* const* wnames, int dtype, int complexity,
+                      int pres_l2_norm, int dilation, int max_level, const int* devices, int ndev);
+int ndwt_mplan_destroy(ndwt_mplan* plan);
+int ndwt_mplan_num_slabs(const ndwt_mplan* plan);
+int ndwt_mplan_slab(const ndwt_mplan* plan, int idx, int* device, int64_t* first_plane, int64_t* planes);
+int ndwt_mdec_host(ndwt_mplan* plan, const void* x_host, void* y_host, int level);
+int ndwt_mrec_host(ndwt_mplan* plan, const void* y_host, void* x_host, int level);
+const char* ndwt_mplan_last_error(void);
+
 /* ---- errors ------------------------------------------------------------------------------------------ */
 const char* ndwt_last_error(void); /* thread-local message of the last failing call */
 const char* ndwt_version(void);

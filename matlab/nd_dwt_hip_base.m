@@ -15,6 +15,7 @@ classdef (Abstract) nd_dwt_hip_base
         compute = 'hip';
         precision = 'double';
         dilation = 'reference';     % 'atrous': textbook SWT (taps dilated by 2^(level-1)); the reference never dilates
+        devices = [];               % HIP device ordinals to shard the outermost axis over (2-D .. 4-D); empty: device 0
     end
     methods (Abstract, Access = protected)
         d = ndim_(obj)                       % number of dimensions
@@ -41,6 +42,7 @@ classdef (Abstract) nd_dwt_hip_base
                     case 'compute',      obj.compute = varargin{ind+1};
                     case 'precision',    obj.precision = varargin{ind+1};
                     case 'dilation',     obj.dilation = varargin{ind+1};
+                    case 'devices',      obj.devices = double(varargin{ind+1}(:).');
                     otherwise, warning(sprintf('Unknown optional input #%d ingoring!', ind));
                 end
             end
@@ -59,12 +61,12 @@ classdef (Abstract) nd_dwt_hip_base
         function y = dec(obj, x, level)
             if obj.ndim_() == 1 && size(x, 1) == 1, x = x.'; end      % nd_dwt_1D.m:151-153
             if strcmpi(obj.precision, 'single'), x = single(x); else, x = double(x); end
-            y = nd_dwt_hip_mex(x, obj.wname(1:obj.ndim_()), 0, level, obj.pres_l2_norm, obj.dilation);
+            y = nd_dwt_hip_mex(x, obj.wname(1:obj.ndim_()), 0, level, obj.pres_l2_norm, obj.dilation, obj.devices);
         end
         function y = rec(obj, x)
             level = obj.level_from_bands_(size(x, obj.ndim_() + 1));
             if strcmpi(obj.precision, 'single'), x = single(x); else, x = double(x); end
-            y = nd_dwt_hip_mex(x, obj.wname(1:obj.ndim_()), 1, level, obj.pres_l2_norm, obj.dilation);
+            y = nd_dwt_hip_mex(x, obj.wname(1:obj.ndim_()), 1, level, obj.pres_l2_norm, obj.dilation, obj.devices);
         end
     end
 end

@@ -4,11 +4,13 @@
  * Replaces reference mex/nd_dwt_mex.c:8-153 for compute = 'hip'.  Same call shape as the reference gateway
  *     y = nd_dwt_mex(x_f, f_dec, dir, level, pres_l2_norm)            (nd_dwt_3D.m:161,225)
  * but the arrays are in the SIGNAL domain and the filters are named, not materialised:
- *     y = nd_dwt_hip_mex(x, wnames, dir, level, pres_l2_norm [, dilation])
+ *     y = nd_dwt_hip_mex(x, wnames, dir, level, pres_l2_norm [, dilation [, devices]])
  *   x        real or complex, single or double; forward: size = sizes; inverse: [sizes, bands]
  *   wnames   cell array of 'dbK', one per axis (1-D: a single string)
  *   dir      0 forward, nonzero inverse                                  (nd_dwt_mex.c:33,106)
  *   dilation optional 'reference' (default) | 'atrous'
+ *   devices  optional vector of HIP device ordinals: the volume is sharded on its outermost axis over them by the
+ *            single-process multi-device plan (ndwt_mplan_*, one slab per entry; 2-D .. 4-D)
  * Complex data: with the interleaved-complex mex API (mex -R2018a, MX_HAS_INTERLEAVED_COMPLEX) the array goes through
  * an NDWT_COMPLEX_INTERLEAVED plan; with the split API of the reference's gateway (mxGetPr / mxGetPi,
  * nd_dwt_mex.c:55-58) the real and imaginary parts go through ndwt_{dec,rec}_split_host on a real plan.
@@ -100,11 +102,54 @@ build:
     return g_cache[victim].plan;
 }
 
+/* one cached multi-device plan (the last configuration used) */
+static struct {
+    ndwt_mplan* plan;
+    int ndim, dtype, cplx, l2, dilation, max_level, ndev;
+    int devices[64];
+    int64_t dims[NDWT_MAX_DIMS];
+    char names[NDWT_MAX_DIMS][16];
+} g_multi;
+
+static void release_multi(void) {
+    if (g_multi.plan) ndwt_mplan_destroy(g_multi.plan);
+    g_multi.plan = NULL;
+}
+
+static ndwt_mplan* get_mplan(int ndim, const int64_t* dims, char names[][16], int dtype, int cplx, int l2, int dilation, int level,
+                             const int* devices, int ndev) {
+    int a, same = g_multi.plan && g_multi.ndim == ndim && g_multi.dtype == dtype && g_multi.cplx == cplx && g_multi.l2 == l2 &&
+                  g_multi.dilation == dilation && g_multi.ndev == ndev && g_multi.max_level >= level;
+    const char* wn[NDWT_MAX_DIMS];
+    static int at_exit = 0;
+    for (a = 0; same && a < ndim; ++a) same = g_multi.dims[a] == dims[a] && !strcmp(g_multi.names[a], names[a]);
+    for (a = 0; same && a < ndev; ++a) same = g_multi.devices[a] == devices[a];
+    if (same) return g_multi.plan;
+    if (!at_exit) {
+        mexAtExit(release_multi);
+        at_exit = 1;
+    }
+    release_multi();
+    for (a = 0; a < ndim; ++a) wn[a] = names[a];
+    if (ndwt_mplan_create(&g_multi.plan, ndim, dims, wn, dtype, cplx, l2, dilation, level < 3 ? 3 : level, devices, ndev) != NDWT_OK) {
+        g_multi.plan = NULL;
+        mexErrMsgIdAndTxt(ERR_ID, "multi-device plan: %s", ndwt_mplan_last_error());
+    }
+    g_multi.ndim = ndim; g_multi.dtype = dtype; g_multi.cplx = cplx; g_multi.l2 = l2; g_multi.dilation = dilation;
+    g_multi.max_level = level < 3 ? 3 : level; g_multi.ndev = ndev;
+    for (a = 0; a < ndim; ++a) {
+        g_multi.dims[a] = dims[a];
+        strcpy(g_multi.names[a], names[a]);
+    }
+    for (a = 0; a < ndev; ++a) g_multi.devices[a] = devices[a];
+    return g_multi.plan;
+}
+
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     const mxArray* x;
     const mwSize* d;
     mwSize nd, od[NDWT_MAX_DIMS + 1], ond;
-    int inverse, level, l2, dilation = NDWT_DILATION_REFERENCE, ndim, a, dtype, cplx, rc;
+    int inverse, level, l2, dilation = NDWT_DILATION_REFERENCE, ndim, a, dtype, cplx, rc, ndev = 0, devices[64];
     int64_t dims[NDWT_MAX_DIMS];
     char names[NDWT_MAX_DIMS][16];
     ndwt_plan* plan;
@@ -121,6 +166,13 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         char buf[16];
         mxGetString(prhs[5], buf, sizeof buf);
         if (!strcmp(buf, "atrous")) dilation = NDWT_DILATION_ATROUS;
+    }
+
+    if (nrhs > 6 && mxGetNumberOfElements(prhs[6]) > 0) {   /* devices: doubles holding device ordinals */
+        const double* dv = (const double*)mxGetData(prhs[6]);
+        ndev = (int)mxGetNumberOfElements(prhs[6]);
+        if (!mxIsDouble(prhs[6]) || ndev > 64) mexErrMsgIdAndTxt(ERR_ID, "devices: a double vector of at most 64 device ordinals");
+        for (a = 0; a < ndev; ++a) devices[a] = (int)dv[a];
     }
 
     /* dims: column vectors are 1-D like nd_dwt_mex.c:68-70; the inverse input carries the band axis last (:115) */
@@ -155,7 +207,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
 #else
     cplx = NDWT_REAL;                                    /* split storage: one real transform per part */
 #endif
-    plan = get_plan(ndim, dims, names, dtype, cplx, l2, dilation, level);
+    plan = ndev > 0 ? NULL : get_plan(ndim, dims, names, dtype, cplx, l2, dilation, level);
 
     /* output: MATLAB-owned, like mxCreateNumericArray at nd_dwt_mex.c:86,136 */
     for (a = 0; a < ndim; ++a) od[a] = (mwSize)dims[a];
@@ -164,6 +216,17 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     if (ond == 1) od[ond++] = 1;
     plhs[0] = mxCreateNumericArray(ond, od, mxIsSingle(x) ? mxSINGLE_CLASS : mxDOUBLE_CLASS, mxIsComplex(x) ? mxCOMPLEX : mxREAL);
 
+    if (ndev > 0) {   /* sharded over the listed devices by the single-process multi-device plan */
+        ndwt_mplan* mp = get_mplan(ndim, dims, names, dtype, cplx, l2, dilation, level, devices, ndev);
+        rc = inverse ? ndwt_mrec_host(mp, mxGetData(x), mxGetData(plhs[0]), level) : ndwt_mdec_host(mp, mxGetData(x), mxGetData(plhs[0]), level);
+#if !MX_HAS_INTERLEAVED_COMPLEX
+        if (rc == NDWT_OK && mxIsComplex(x))          /* split storage: the imaginary part is a second real transform */
+            rc = inverse ? ndwt_mrec_host(mp, mxGetImagData(x), mxGetImagData(plhs[0]), level)
+                         : ndwt_mdec_host(mp, mxGetImagData(x), mxGetImagData(plhs[0]), level);
+#endif
+        if (rc != NDWT_OK) mexErrMsgIdAndTxt(ERR_ID, "%s: %s", inverse ? "rec" : "dec", ndwt_mplan_last_error());
+        return;
+    }
 #if MX_HAS_INTERLEAVED_COMPLEX
     rc = inverse ? ndwt_rec_host(plan, mxGetData(x), mxGetData(plhs[0]), level)
                  : ndwt_dec_host(plan, mxGetData(x), mxGetData(plhs[0]), level);

@@ -26,7 +26,8 @@ EXPORTS = [
     "ndwt_rec_host", "ndwt_shrink", "ndwt_denoise", "ndwt_denoise_host", "ndwt_dec_split", "ndwt_rec_split", "ndwt_dec_split_host", "ndwt_rec_split_host", "ndwt_slab_halo", "ndwt_analysis_level_slab", "ndwt_synthesis_level_slab",
     "ndwt_analysis_level_slab_split", "ndwt_synthesis_level_slab_ext", "ndwt_analysis_level_slab_part",
     "ndwt_synthesis_level_slab_part", "ndwt_analysis_level_slab_runs", "ndwt_synthesis_level_slab_runs", "ndwt_last_error",
-    "ndwt_version",
+    "ndwt_version", "ndwt_mplan_create", "ndwt_mplan_destroy", "ndwt_mplan_num_slabs", "ndwt_mplan_slab", "ndwt_mdec_host",
+    "ndwt_mrec_host", "ndwt_mplan_last_error",
 ]
 
 
@@ -103,6 +104,15 @@ def lib() -> ctypes.CDLL:
                                                 ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
     L.ndwt_synthesis_level_slab_runs.argtypes = [ctypes.c_void_p, c_void_pp] + [ctypes.c_int64] * 5 + [ctypes.c_void_p, ctypes.c_int,
                                                                                                     ctypes.c_void_p]
+    L.ndwt_mplan_create.argtypes = [c_void_pp, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_char_p), ctypes.c_int,
+                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    L.ndwt_mplan_destroy.argtypes = [ctypes.c_void_p]
+    L.ndwt_mplan_num_slabs.argtypes = [ctypes.c_void_p]
+    L.ndwt_mplan_slab.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64),
+                                  ctypes.POINTER(ctypes.c_int64)]
+    for f in (L.ndwt_mdec_host, L.ndwt_mrec_host):
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    L.ndwt_mplan_last_error.restype = ctypes.c_char_p
     L.ndwt_last_error.restype = ctypes.c_char_p
     L.ndwt_version.restype = ctypes.c_char_p
     _lib = L
@@ -112,6 +122,11 @@ def lib() -> ctypes.CDLL:
 def check(rc: int):
     if rc != NDWT_OK:
         raise NdwtError(rc, lib().ndwt_last_error().decode())
+
+
+def mcheck(rc: int):
+    if rc != NDWT_OK:
+        raise NdwtError(rc, lib().ndwt_mplan_last_error().decode())
 
 
 def wave_filters(wname: str):

@@ -156,6 +156,66 @@ class Plan:
         L.check(L.lib().ndwt_synthesis_level_slab(self._h, arr, out_ptr, int(stride), ctypes.c_void_p(stream)))
 
 
+class MultiPlan:
+    """Single-process multi-device plan (include/ndwt.h, ndwt_mplan_*): ONE host thread drives the listed devices; the volume is
+    sharded in slabs on its outermost axis (a device listed twice holds two slabs).  Host arrays in kernel order
+    ((bands,) nd, ..., n1, contiguous) in and out -- the path behind the MATLAB gateway, where the host is one process."""
+
+    def __init__(self, dims, wnames, dtype, devices, complex_interleaved=False, pres_l2_norm=False, dilation="reference", max_level=3):
+        self.dims = [int(d) for d in dims]
+        self.ndim = len(self.dims)
+        self.np_dtype = np.float32 if dtype in (torch.float32, np.float32, "single") else np.float64
+        self.complex = bool(complex_interleaved)
+        self.max_level = int(max_level)
+        self._h = ctypes.c_void_p(None)
+        dims_c = (ctypes.c_int64 * self.ndim)(*self.dims)
+        names_c = (ctypes.c_char_p * self.ndim)(*[w.encode() for w in wnames])
+        devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        dt = L.NDWT_F32 if self.np_dtype == np.float32 else L.NDWT_F64
+        dil = {"reference": L.NDWT_DILATION_REFERENCE, "atrous": L.NDWT_DILATION_ATROUS}[dilation]
+        L.mcheck(L.lib().ndwt_mplan_create(ctypes.byref(self._h), self.ndim, dims_c, names_c, dt,
+                                           L.NDWT_COMPLEX_INTERLEAVED if self.complex else L.NDWT_REAL, int(bool(pres_l2_norm)), dil,
+                                           self.max_level, devs, len(devices)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                L.lib().ndwt_mplan_destroy(self._h)
+                self._h = ctypes.c_void_p(None)
+        except Exception:
+            pass
+
+    def slabs(self):
+        out = []
+        for i in range(L.lib().ndwt_mplan_num_slabs(self._h)):
+            d, z0, n = ctypes.c_int(0), ctypes.c_int64(0), ctypes.c_int64(0)
+            L.mcheck(L.lib().ndwt_mplan_slab(self._h, i, ctypes.byref(d), ctypes.byref(z0), ctypes.byref(n)))
+            out.append((d.value, z0.value, n.value))
+        return out
+
+    def _check(self, a, bands):
+        cdt = {np.float32: np.complex64, np.float64: np.complex128}[self.np_dtype] if self.complex else self.np_dtype
+        shape = ((bands,) if bands else ()) + tuple(reversed(self.dims))
+        if not (isinstance(a, np.ndarray) and a.dtype == cdt and a.flags.c_contiguous and a.shape == shape):
+            raise ValueError(f"expected a C-contiguous {np.dtype(cdt).name} array of shape {shape}")
+
+    def dec(self, x, level):
+        """x: numpy (nd, ..., n1) -> numpy (bands, nd, ..., n1)"""
+        self._check(x, 0)
+        y = np.empty((num_bands(self.ndim, level),) + x.shape, dtype=x.dtype)
+        L.mcheck(L.lib().ndwt_mdec_host(self._h, x.ctypes.data_as(ctypes.c_void_p), y.ctypes.data_as(ctypes.c_void_p), int(level)))
+        return y
+
+    def rec(self, y):
+        level = L.lib().ndwt_level_from_bands(self.ndim, int(y.shape[0]))
+        if level < 1:
+            raise ValueError(f"{y.shape[0]} bands is not a valid {self.ndim}-D coefficient count")
+        self._check(y, y.shape[0])
+        x = np.empty(y.shape[1:], dtype=y.dtype)
+        L.mcheck(L.lib().ndwt_mrec_host(self._h, y.ctypes.data_as(ctypes.c_void_p), x.ctypes.data_as(ctypes.c_void_p), level))
+        return x
+
+
 def num_bands(ndim, level):
     return int(L.lib().ndwt_num_bands(int(ndim), int(level)))
 
@@ -181,6 +241,7 @@ class _NdDwtBase:
         self.compute = "hip"
         self.dilation = "reference"
         self.device = None
+        self.devices = None
         # name/value pairs as in MATLAB (nd_dwt_3D.m:105-120); keyword arguments are accepted too
         if len(varargin) % 2:
             raise ValueError("Optional inputs must come in pairs")
@@ -197,6 +258,8 @@ class _NdDwtBase:
                 self.dilation = str(val).lower()
             elif k == "device":
                 self.device = val
+            elif k == "devices":                   # shard the outermost axis over these devices (host arrays, one process)
+                self.devices = [int(v) for v in np.atleast_1d(val)]
             else:   # unknown keys only warn (nd_dwt_3D.m:118)
                 warnings.warn(f"Unknown optional input #{2 * ind + 1} ingoring!")
         if self.compute.lower() == "mex" and self.precision.lower() == "single":   # nd_dwt_3D.m:122-124
@@ -212,6 +275,8 @@ class _NdDwtBase:
             raise ValueError("precision must be 'double' or 'single'")
         if self.dilation not in ("reference", "atrous"):
             raise ValueError("dilation must be 'reference' or 'atrous'")
+        if self.devices is not None and (not self._offload or d < 2):
+            raise ValueError("'devices' shards host arrays of 2-D .. 4-D transforms: use compute='hip_off'")
         # get_filters (nd_dwt_3D.m:263-342): per-axis taps instead of N-D FFT-domain kernels
         self.f_dec = [L.wave_filters(w) for w in self.wname[:d]]
         self.f_size = {f"s{a + 1}": len(self.f_dec[a][0]) for a in range(d)}
@@ -289,6 +354,8 @@ class _NdDwtBase:
         x = self._prep_dec_input(x)
         if list(x.shape) != self.sizes:
             raise ValueError(f"input size {list(x.shape)} does not match the object's sizes {self.sizes}")
+        if self.devices is not None:
+            return self._multi(x, level, None)
         dev = self._dev(x if isinstance(x, torch.Tensor) else None)
         xk = self._to_device_kernel_order(x, dev, self.NDIM)
         is_c = xk.is_complex()
@@ -307,6 +374,8 @@ class _NdDwtBase:
         level = self._level_from_bands(int(y.shape[-1]))
         if num_bands(self.NDIM, level) != int(y.shape[-1]):
             raise ValueError(f"{int(y.shape[-1])} bands is not a valid {self.NDIM}-D coefficient count")
+        if self.devices is not None:
+            return self._multi(y, level, "rec")
         dev = self._dev(y if isinstance(y, torch.Tensor) else None)
         yk = self._to_device_kernel_order(y, dev, self.NDIM + 1)
         plan = self._plan(yk.is_complex(), level, dev)
@@ -355,6 +424,23 @@ class _NdDwtBase:
 
     def _prep_dec_input(self, x):
         return x
+
+    def _multi(self, a, level, direction):
+        """host array through the single-process multi-device plan (the 'devices' option)"""
+        like_numpy = isinstance(a, np.ndarray)
+        an = a if like_numpy else a.cpu().numpy()
+        cplx = np.iscomplexobj(an)
+        single = self.precision.lower() == "single"
+        cdt = (np.complex64 if single else np.complex128) if cplx else (np.float32 if single else np.float64)
+        ak = np.ascontiguousarray(np.transpose(an)).astype(cdt, copy=False)
+        key = ("multi", cplx)
+        mp = self._plans.get(key)
+        if mp is None or mp.max_level < level:
+            mp = MultiPlan(self.sizes, self.wname[: self.NDIM], torch.float32 if single else torch.float64, self.devices, cplx,
+                           self.pres_l2_norm, self.dilation, max_level=max(level, 3))
+            self._plans[key] = mp
+        out = np.transpose(mp.rec(ak) if direction == "rec" else mp.dec(ak, level))
+        return out if like_numpy else torch.from_numpy(np.ascontiguousarray(out))
 
 
 class nd_dwt_1D(_NdDwtBase):

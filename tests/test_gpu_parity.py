@@ -640,6 +640,58 @@ def test_slab_plan_checks_the_whole_axis_not_the_slab():
         api.Plan([32, 32, 16, 4], ["db4"] * 4, torch.float32, global_outer=3)
 
 
+@pytest.mark.parametrize("dims,wn,level,precision,cplx,dilation,nslab,exact", [
+    ([72, 40, 50], ["db4", "db4", "db4"], 3, "single", False, "reference", 3, True),      # fused 3-D slabs, uneven 16 / 17 / 17 planes
+    ([40, 24, 18], ["db2", "db1", "db6"], 2, "double", False, "reference", 4, True),      # thinner than the 12-tap filter: multi-hop halos
+    ([24, 20, 12, 16], ["db4"] * 4, 2, "single", False, "reference", 4, True),            # 4-D, 4 frames per slab under 8 taps (cfg5's regime)
+    # the slab kernels of these three differ from the single-device ones (outer filter shorter than the padded length; dilated
+    # sub-lattice kernels; 2-D): same numbers to rounding, not bit for bit
+    ([36, 30, 16], ["db3", "db2", "db2"], 2, "double", True, "reference", 2, False),      # interleaved complex
+    ([24, 20, 16], ["db2", "db2", "db2"], 3, "single", False, "atrous", 2, False),        # dilated taps: halo of 8 planes at level 3
+    ([70, 45], ["db2", "db4"], 3, "double", False, "reference", 3, False),                # 2-D, sharded on its second axis
+])
+def test_single_process_multi_device_plan(dims, wn, level, precision, cplx, dilation, nslab, exact):
+    """ndwt_mplan_*: one host thread, several slabs (here all on the one GPU: a device may be listed more than once), halo
+    planes moved between slabs by device-to-device copies ordered with events.  Gather exchange in both directions: where the
+    slab and the single-device transform run the same kernels the results are equal BIT FOR BIT; always the oracle's within the
+    usual tolerance."""
+    import ctypes
+    api = __import__("importlib").import_module("non-decimated_wavelets_amd.api")
+    d = len(dims)
+    rng = np.random.default_rng(88)
+    x = rng.standard_normal(dims) + (1j * rng.standard_normal(dims) if cplx else 0)
+    rdt = np.float32 if precision == "single" else np.float64
+    cdt = (np.complex64 if precision == "single" else np.complex128) if cplx else rdt
+    xk = np.ascontiguousarray(x.T).astype(cdt)
+    tdt = torch.float32 if precision == "single" else torch.float64
+    mp = api.MultiPlan(dims, wn, tdt, [0] * nslab, cplx, True, dilation, max_level=level)
+    sl = mp.slabs()
+    assert len(sl) == nslab and sl[0][1] == 0 and sum(s[2] for s in sl) == dims[-1]
+    yk = mp.dec(xk, level)
+    want = orc.spatial_dec(x, wn, level, 1, dilation)
+    assert _relerr(yk.T, want) <= TOL[precision]
+    # the single-device host entry points on the same data
+    p1 = api.Plan(dims, wn, tdt, cplx, True, dilation, max_level=level)
+    y1 = np.empty_like(yk)
+    ndwt._lib.check(ndwt.lib().ndwt_dec_host(p1._h, xk.ctypes.data_as(ctypes.c_void_p), y1.ctypes.data_as(ctypes.c_void_p), level))
+    assert np.array_equal(yk, y1) if exact else _relerr(yk, y1) <= TOL[precision]
+    c = (rng.standard_normal(yk.shape) + (1j * rng.standard_normal(yk.shape) if cplx else 0)).astype(cdt)
+    r = mp.rec(c)
+    r1 = np.empty_like(r)
+    ndwt._lib.check(ndwt.lib().ndwt_rec_host(p1._h, c.ctypes.data_as(ctypes.c_void_p), r1.ctypes.data_as(ctypes.c_void_p), level))
+    assert np.array_equal(r, r1) if exact else _relerr(r, r1) <= 4 * TOL[precision]
+    assert _relerr(r.T, orc.spatial_rec(np.transpose(c), wn, 1, dilation)) <= 4 * TOL[precision]
+    assert _relerr(mp.rec(yk), xk) <= 20 * TOL[precision]
+    with pytest.raises(ndwt.NdwtError, match="max_level"):
+        mp.dec(xk, level + 1)
+    # the same through the class API: the 'devices' option of the drop-in classes (host arrays, compute = 'hip_off')
+    w = _cls(d)(wn, dims, "pres_l2_norm", 1, "precision", precision, "dilation", dilation, "compute", "hip_off", "devices", [0] * nslab)
+    yc = w.dec(x, level)
+    assert isinstance(yc, np.ndarray) and yc.shape == tuple(dims) + (orc.num_bands(d, level),)
+    assert np.array_equal(yc, yk.T)
+    assert _relerr(w.rec(yc), x) <= 20 * TOL[precision]
+
+
 def _run_ranks(worker, world):
     import socket
     import torch.multiprocessing as mp
