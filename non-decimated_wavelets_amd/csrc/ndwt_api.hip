@@ -378,7 +378,7 @@ void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int
 // signs), which holds for the zero-padded taps of an axis when its padding (Lp - len) / 2 is even; it keeps plane offsets in
 // 32-bit BYTE counts.  variant_inv 4 forces the older lane-shift kernel (Inv3S) for A/B runs.
 template <typename T> static bool inv3y_eligible(const ndwt_plan* p, int Lp, const Fused3Args<T>& a) {
-    if (p->dtype != NDWT_F32 || p->comp != 1 || Lp > 8 || p->variant_inv == 3 || p->variant_inv == 4) return false;
+    if (p->dtype != NDWT_F32 || p->comp != 1 || Lp > 12 || p->variant_inv == 3 || p->variant_inv == 4) return false;
     for (int ax = 0; ax < 3; ++ax)
         if (((Lp - p->filt[ax].len) / 2) % 2 != 0) return false;
     return (long long)a.rs * a.n2 < (1LL << 30);

@@ -1,4 +1,4 @@
-// fused 3-D inv level, float, real data, stride 1: the pair-packed lane-shift kernel (Inv3Y), tap lengths 2..8
+// fused 3-D inv level, float, real data, stride 1: the pair-packed lane-shift kernel (Inv3Y), tap lengths 2..12
 #include "ndwt_fused_kernels.h"
 namespace ndwt {
 
@@ -10,7 +10,7 @@ template <int LL, bool V, int DEPTH> static int go(const Fused3Args<float>& a, c
 }
 
 // depth 2 (two register sets of band loads, staggered refill) is the default where it fits the 128 registers of a 1024-thread
-// workgroup without spills (tap lengths 2 and 8; 4 and 6 spill a few registers, and a spill reload in the plane loop waits
+// workgroup without spills (tap lengths 2, 8 and 10; 4, 6 and 12 spill a few registers, and a spill reload in the plane loop waits
 // vmcnt(0), i.e. for every load in flight); depth 1 serves the others, unaligned volumes and A/B runs
 #define NDWT_INVY_CASE(LL, D2OK) \
     case LL:                     \
@@ -26,6 +26,8 @@ int launch_inv3y_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, c
         NDWT_INVY_CASE(2, true)
         NDWT_INVY_CASE(4, false)
         NDWT_INVY_CASE(6, false)
+        NDWT_INVY_CASE(10, true)
+        NDWT_INVY_CASE(12, false)
 #endif
         default: return -1;
     }

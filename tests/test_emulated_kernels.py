@@ -106,8 +106,11 @@ CASES_Y = [
     ((13, 10, 9), ("db2", "db2", "db2"), False, 4, True),
     ((20, 17, 12), ("db4", "db4", "db4"), True, 5, True),
     ((24, 19, 11), ("db6", "db2", "db4"), True, 0, True),        # two-hop lane shifts
-    ((68, 39, 9), ("db4", "db4", "db4"), True, 0, False),        # production tile shape (db4 only): ragged in x and y
+    ((68, 39, 9), ("db4", "db4", "db4"), True, 0, False),        # production tile shape (8 and 12 taps): ragged in x and y
     ((70, 60, 10), ("db2", "db2", "db4"), False, 6, False),
+    ((24, 21, 13), ("db5", "db5", "db5"), True, 0, True),
+    ((21, 14, 12), ("db5", "db3", "db1"), False, 5, True),
+    ((72, 37, 12), ("db6", "db6", "db6"), True, 0, False),       # production tile shape, 12 taps: 15 of the 16 waves hold rows
 ]
 
 
