@@ -38,6 +38,8 @@ def parse_args():
     ap.add_argument("--level", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--generic", action="store_true", help="force the per-axis kernels (for comparison)")
+    ap.add_argument("--band-pitch", default="packed", choices=["packed", "auto"],
+                    help="layout of the coefficient buffer between dec and rec: packed = the reference's; auto = ndwt_band_pitch()")
     ap.add_argument("--zchunk", type=int, default=0)
     ap.add_argument("--target-blocks", type=int, default=0)
     a = ap.parse_args()
@@ -151,13 +153,15 @@ def main():
         plan.set_path(a.generic)
         plan.set_tuning(a.target_blocks, a.zchunk)
         x = torch.randn(kshape, device=dev, dtype=torch.float32)
-        y = torch.empty((nbands,) + kshape, device=dev, dtype=torch.float32)
+        pitch = plan.band_pitch() if a.band_pitch == "auto" else 0
+        y = torch.empty(nbands * (pitch if pitch else V), device=dev, dtype=torch.float32)
         r = torch.empty_like(x)
         stream = torch.cuda.current_stream(dev).cuda_stream
+        lay = {"pitch": pitch, "y": y}
 
         def step():
-            plan.dec(x.data_ptr(), y.data_ptr(), level, stream)
-            plan.rec(y.data_ptr(), r.data_ptr(), level, stream)
+            plan.dec(x.data_ptr(), lay["y"].data_ptr(), level, stream, band_pitch=lay["pitch"])
+            plan.rec(lay["y"].data_ptr(), r.data_ptr(), level, stream, band_pitch=lay["pitch"])
     else:
         sh = importlib.import_module("non-decimated_wavelets_amd.sharded")
         eng = sh.ShardedNdDwt([a.wname] * d, sizes, pres_l2_norm=True, precision="single", group=None, device=dev,
@@ -241,7 +245,7 @@ def main():
     # not the profiled configuration
     traffic, traffic_src = None, None
     try:
-        if not sharded and d == 3 and sizes == [512, 512, 512] and a.wname == "db4" and level == 3 and not a.generic:
+        if not sharded and d == 3 and sizes == [512, 512, 512] and a.wname == "db4" and level == 3 and not a.generic and a.band_pitch == "packed":
             tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
             traffic = tj[drow["kernel"]]["traffic_bytes"]
             traffic_src = "profiles/r02_traffic.json"
@@ -253,6 +257,32 @@ def main():
                 "other_kernels": [rows[k] for k in rows if k != dom and rows[k] is not None],
                 "whole_step_frac": round(step_bytes / (dt / a.steps) / 1e9 / (HBM_PEAK_GBS * world), 4)}
 
+    # the same step with the coefficient buffer pitched (include/ndwt.h: ndwt_dec_pitched): what a caller that owns the buffer
+    # gets; reported beside the headline, which keeps the reference's packed layout
+    pitched = None
+    if not sharded and a.band_pitch == "packed":
+        lay["y"] = y = None
+        lay["pitch"] = plan.band_pitch()
+        lay["y"] = torch.empty(nbands * lay["pitch"], device=dev, dtype=torch.float32)
+        for _ in range(2):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        fence()
+        dtp = time.perf_counter() - t0
+        plan.set_profiling(True)
+        for _ in range(prof_steps):
+            step()
+        torch.cuda.synchronize(dev)
+        pp = {k: plan.get_profile(k) for k in KERNEL_NAMES}
+        plan.set_profiling(False)
+        pitched = {"band_pitch_elements": lay["pitch"], "ms_per_step": round(dtp / a.steps * 1e3, 4), "value": round(V / (dtp / a.steps) / 1e6, 1),
+                   "whole_step_frac": round(step_bytes / (dtp / a.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                   "avg_launch_ms": {KERNEL_NAMES[k]: round(pp[k][0] / pp[k][1], 4) for k in pp if pp[k][1]},
+                   "roundtrip_rel_l2": float(torch.linalg.vector_norm((r - x).double()) / torch.linalg.vector_norm(x.double()))}
+
     shape = "x".join(str(n) for n in sizes)
     cube = f"{sizes[0]}^3" if d == 3 and len(set(sizes)) == 1 else shape
     out = {"metric": f"Mvoxels/s fwd+inv NDWT ({cube} fp32, {level} lvl {a.wname})", "value": round(value, 1), "unit": "Mvoxels/s",
@@ -261,8 +291,11 @@ def main():
            "config": {"workload": f"{d}D fp32 {shape} {a.wname} {level} levels, dec+rec, pres_l2_norm, reference dilation (stride 1)",
                       "sharding": "none" if world == 1 else f"outer-axis slabs x{world}; per level: analysis halo fetch (1 band) and synthesis "
                                                               f"scatter-add (1 band) via RCCL send/recv, overlapped with the interior planes",
-                      "path": "per-axis" if a.generic else ("fused3d" if d == 3 else "t-axis march + fused3d")},
+                      "path": "per-axis" if a.generic else ("fused3d" if d == 3 else "t-axis march + fused3d"),
+                      "coefficient_layout": "packed (reference)" if a.band_pitch == "packed" or sharded else "pitched bands (ndwt_band_pitch)"},
            "roofline": roofline, "roundtrip_rel_l2": rt_err}
+    if pitched is not None:
+        out["pitched_coefficients"] = pitched
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cores = os.cpu_count() or 1
         workers = min(cores, 16)

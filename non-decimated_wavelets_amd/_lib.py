@@ -27,7 +27,7 @@ EXPORTS = [
     "ndwt_analysis_level_slab_split", "ndwt_synthesis_level_slab_ext", "ndwt_analysis_level_slab_part",
     "ndwt_synthesis_level_slab_part", "ndwt_analysis_level_slab_runs", "ndwt_synthesis_level_slab_runs", "ndwt_last_error",
     "ndwt_version", "ndwt_mplan_create", "ndwt_mplan_destroy", "ndwt_mplan_num_slabs", "ndwt_mplan_slab", "ndwt_mdec_host",
-    "ndwt_mrec_host", "ndwt_mplan_last_error",
+    "ndwt_mrec_host", "ndwt_mplan_last_error", "ndwt_dec_pitched", "ndwt_rec_pitched", "ndwt_shrink_pitched", "ndwt_band_pitch",
 ]
 
 
@@ -83,6 +83,11 @@ def lib() -> ctypes.CDLL:
     for f in (L.ndwt_dec_host, L.ndwt_rec_host):
         f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     L.ndwt_shrink.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_void_p]
+    L.ndwt_dec_pitched.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+    L.ndwt_rec_pitched.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    L.ndwt_shrink_pitched.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_void_p]
+    L.ndwt_band_pitch.argtypes = [ctypes.c_void_p]
+    L.ndwt_band_pitch.restype = ctypes.c_int64
     L.ndwt_denoise.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_int,
                                ctypes.c_void_p]
     L.ndwt_denoise_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_int]

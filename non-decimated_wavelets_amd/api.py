@@ -83,15 +83,20 @@ class Plan:
         L.check(L.lib().ndwt_plan_describe(self._h, buf, 64))
         return buf.value.decode()
 
-    def dec(self, x_ptr, y_ptr, level, stream=0):
-        L.check(L.lib().ndwt_dec(self._h, x_ptr, y_ptr, int(level), ctypes.c_void_p(stream)))
+    def band_pitch(self) -> int:
+        """recommended band pitch of a pitched coefficient buffer, in elements (include/ndwt.h: ndwt_band_pitch)"""
+        return int(L.lib().ndwt_band_pitch(self._h))
 
-    def rec(self, y_ptr, x_ptr, level, stream=0):
-        L.check(L.lib().ndwt_rec(self._h, y_ptr, x_ptr, int(level), ctypes.c_void_p(stream)))
+    def dec(self, x_ptr, y_ptr, level, stream=0, band_pitch=0):
+        """band_pitch: elements between consecutive bands of y (0 = packed, the reference layout)"""
+        L.check(L.lib().ndwt_dec_pitched(self._h, x_ptr, y_ptr, int(band_pitch), int(level), ctypes.c_void_p(stream)))
 
-    def shrink(self, y_ptr, level, threshold, hard=False, stream=0):
+    def rec(self, y_ptr, x_ptr, level, stream=0, band_pitch=0):
+        L.check(L.lib().ndwt_rec_pitched(self._h, y_ptr, int(band_pitch), x_ptr, int(level), ctypes.c_void_p(stream)))
+
+    def shrink(self, y_ptr, level, threshold, hard=False, stream=0, band_pitch=0):
         """in-place soft (default) / hard thresholding of the detail bands"""
-        L.check(L.lib().ndwt_shrink(self._h, y_ptr, int(level), float(threshold), int(bool(hard)), ctypes.c_void_p(stream)))
+        L.check(L.lib().ndwt_shrink_pitched(self._h, y_ptr, int(band_pitch), int(level), float(threshold), int(bool(hard)), ctypes.c_void_p(stream)))
 
     def denoise(self, x_ptr, out_ptr, level, threshold, hard=False, stream=0):
         """dec -> shrink -> rec with the coefficients in a scratch array owned by the plan"""
@@ -242,6 +247,7 @@ class _NdDwtBase:
         self.dilation = "reference"
         self.device = None
         self.devices = None
+        self.band_pitch = "packed"
         # name/value pairs as in MATLAB (nd_dwt_3D.m:105-120); keyword arguments are accepted too
         if len(varargin) % 2:
             raise ValueError("Optional inputs must come in pairs")
@@ -258,6 +264,8 @@ class _NdDwtBase:
                 self.dilation = str(val).lower()
             elif k == "device":
                 self.device = val
+            elif k == "band_pitch":                # 'packed' (reference layout) | 'auto' | elements between bands of dec()'s result
+                self.band_pitch = val if isinstance(val, str) else int(val)
             elif k == "devices":                   # shard the outermost axis over these devices (host arrays, one process)
                 self.devices = [int(v) for v in np.atleast_1d(val)]
             else:   # unknown keys only warn (nd_dwt_3D.m:118)
@@ -275,6 +283,10 @@ class _NdDwtBase:
             raise ValueError("precision must be 'double' or 'single'")
         if self.dilation not in ("reference", "atrous"):
             raise ValueError("dilation must be 'reference' or 'atrous'")
+        if isinstance(self.band_pitch, str) and self.band_pitch.lower() not in ("packed", "auto"):
+            raise ValueError("band_pitch must be 'packed', 'auto' or a number of elements")
+        if self.band_pitch != "packed" and self._offload:
+            raise ValueError("'band_pitch' lays out device tensors: use compute='hip'")
         if self.devices is not None and (not self._offload or d < 2):
             raise ValueError("'devices' shards host arrays of 2-D .. 4-D transforms: use compute='hip_off'")
         # get_filters (nd_dwt_3D.m:263-342): per-axis taps instead of N-D FFT-domain kernels
@@ -361,10 +373,39 @@ class _NdDwtBase:
         is_c = xk.is_complex()
         plan = self._plan(is_c, level, dev)
         nb = num_bands(self.NDIM, level)
-        yk = torch.empty((nb,) + tuple(xk.shape), dtype=xk.dtype, device=dev)
+        vol = int(np.prod(xk.shape))
+        pitch = self._pitch(plan, vol)
+        if pitch:
+            # a pitched coefficient tensor: same shape and indexing, band b at b * pitch elements (a view of one allocation);
+            # .contiguous() gives the packed reference layout
+            flat = torch.empty(nb * pitch, dtype=xk.dtype, device=dev)
+            cs = [1] * xk.dim()
+            for i in range(xk.dim() - 2, -1, -1):
+                cs[i] = cs[i + 1] * int(xk.shape[i + 1])
+            yk = flat.as_strided((nb,) + tuple(xk.shape), (pitch,) + tuple(cs))
+        else:
+            yk = torch.empty((nb,) + tuple(xk.shape), dtype=xk.dtype, device=dev)
         with torch.cuda.device(dev):
-            plan.dec(xk.data_ptr(), yk.data_ptr(), level, _current_stream(dev))
+            plan.dec(xk.data_ptr(), yk.data_ptr(), level, _current_stream(dev), band_pitch=pitch)
         return self._from_device(yk, like_numpy, dev)   # real in -> real out (nd_dwt_3D.m:189-192) by construction
+
+    def _pitch(self, plan, vol):
+        if self.band_pitch == "packed":
+            return 0
+        if isinstance(self.band_pitch, str):
+            return plan.band_pitch()
+        if self.band_pitch < vol:
+            raise ValueError(f"band_pitch {self.band_pitch} is smaller than a band ({vol} elements)")
+        return 0 if self.band_pitch == vol else int(self.band_pitch)
+
+    def _coef_kernel_order(self, y, dev):
+        """coefficient array (MATLAB shape [dims, bands]) -> (tensor in kernel order, band pitch): a device tensor whose bands are
+        each contiguous and evenly spaced (what dec() returns, packed or pitched) is used where it lies"""
+        if isinstance(y, torch.Tensor) and y.is_cuda and y.device == dev and y.dtype == self._torch_dtype(y.is_complex()):
+            yk = y.permute(*reversed(range(y.dim())))
+            if yk[0].is_contiguous() and yk.shape[0] > 1 and yk.stride(0) > yk[0].numel():
+                return yk, int(yk.stride(0))
+        return self._to_device_kernel_order(y, dev, self.NDIM + 1), 0
 
     # -- nd_dwt_3D.m:202-256 --
     def rec(self, y):
@@ -377,11 +418,11 @@ class _NdDwtBase:
         if self.devices is not None:
             return self._multi(y, level, "rec")
         dev = self._dev(y if isinstance(y, torch.Tensor) else None)
-        yk = self._to_device_kernel_order(y, dev, self.NDIM + 1)
+        yk, pitch = self._coef_kernel_order(y, dev)
         plan = self._plan(yk.is_complex(), level, dev)
         xk = torch.empty(tuple(yk.shape[1:]), dtype=yk.dtype, device=dev)
         with torch.cuda.device(dev):
-            plan.rec(yk.data_ptr(), xk.data_ptr(), level, _current_stream(dev))
+            plan.rec(yk.data_ptr(), xk.data_ptr(), level, _current_stream(dev), band_pitch=pitch)
         return self._from_device(xk, like_numpy, dev)
 
     # -- consumers for iterative solvers (extension; not in the reference) --
@@ -395,12 +436,18 @@ class _NdDwtBase:
             raise ValueError(f"coefficient array must have shape {self.sizes + ['bands']}")
         level = self._level_from_bands(int(y.shape[-1]))
         dev = self._dev(y if isinstance(y, torch.Tensor) else None)
-        yk = self._to_device_kernel_order(y, dev, self.NDIM + 1)
+        yk, pitch = self._coef_kernel_order(y, dev)
         if isinstance(y, torch.Tensor) and yk.data_ptr() == y.data_ptr():
-            yk = yk.clone()                                    # never modify the caller's array
+            if pitch:                                          # never modify the caller's array: copy, keeping the pitch
+                flat = torch.empty(yk.shape[0] * pitch, dtype=yk.dtype, device=dev)
+                cp = flat.as_strided(tuple(yk.shape), tuple(yk.stride()))
+                cp.copy_(yk)
+                yk = cp
+            else:
+                yk = yk.clone()
         plan = self._plan(yk.is_complex(), level, dev)
         with torch.cuda.device(dev):
-            plan.shrink(yk.data_ptr(), level, threshold, mode == "hard", _current_stream(dev))
+            plan.shrink(yk.data_ptr(), level, threshold, mode == "hard", _current_stream(dev), band_pitch=pitch)
         return self._from_device(yk, like_numpy, dev)
 
     def denoise(self, x, level, threshold, mode="soft"):

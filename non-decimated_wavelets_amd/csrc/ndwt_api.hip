@@ -410,6 +410,16 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     const int nin = inverse ? 8 : (z_mode == 2 ? 3 : 1), nout = inverse ? 1 : 8;
     for (int b = 0; b < nin; ++b) { a.in[b] = in[b]; vec4 = vec4 && aligned_vec4<T>(in[b]); }
     for (int b = 0; b < nout; ++b) { a.out[b] = out[b]; vec4 = vec4 && aligned_vec4<T>(out[b]); }
+#ifdef NDWT_EXP_BANDPAD   // diagnostic build (timing only, results are garbage): skew the band streams against each other
+    if (const char* v = getenv("NDWT_EXP_BANDPAD")) {
+        const long long pad = atoll(v);
+        const int div = getenv("NDWT_EXP_BANDDIV") ? atoi(getenv("NDWT_EXP_BANDDIV")) : 1;   // bands b, b+1, .. b+div-1 keep their distance
+        const int mask = getenv("NDWT_EXP_BANDMASK") ? (int)strtol(getenv("NDWT_EXP_BANDMASK"), nullptr, 0) : 0;   // these bands get +pad
+        if (inverse && mask) for (int b = 0; b < nin; ++b) a.in[b] = in[b] + ((mask >> b) & 1) * pad;
+        else if (inverse) for (int b = 0; b < nin; ++b) a.in[b] = in[b] + (b / div) * pad;
+        else for (int b = 0; b < nout; ++b) a.out[b] = out[b] + (b / div) * pad;
+    }
+#endif
     int TX = 0, TY = 0;
     const int variant = inverse ? p->variant_inv : p->variant_fwd;
     const int ew = dil > 1 ? dil : (int)p->comp;
@@ -520,10 +530,11 @@ static int analysis_level(ndwt_plan* p, const T* in, T* const* out, long long st
             return fused3_run<T>(p, false, Lp, ins, out, p->dims[2], 1, vol_in, p->vol, slab ? 0 : 1, s);
         }
         // d == 4: outer axis per-axis (1 -> 2), then the fused 3-D kernel on both halves, batched over n4
-        int rc = ensure_tmp(p, (size_t)(2 * p->vol) * sizeof(T));
+        const long long skew = 256 / (long long)sizeof(T);   // the two halves 256 B off a power-of-two distance (see ndwt_band_pitch)
+        int rc = ensure_tmp(p, (size_t)(2 * p->vol + skew) * sizeof(T));
         if (rc) return rc;
         T* lo = (T*)p->tmp;
-        T* hi = lo + p->vol;
+        T* hi = lo + p->vol + skew;
         rc = axis_pass<T>(p, false, 3, p->dims, stride, !slab, in, nullptr, lo, hi, s);
         if (rc) return rc;
         const T* ins_lo[8] = {lo};
@@ -571,10 +582,11 @@ static int synthesis_level(ndwt_plan* p, const T* const* in, T* out, long long s
             T* outs[8] = {out};
             return fused3_run<T>(p, true, Lp, in, outs, p->dims[2], 1, vol_in, p->vol, slab ? 0 : 1, s, 0, LLONG_MIN, 0, 0xFE);
         }
-        int rc = ensure_tmp(p, (size_t)(2 * vol_in) * sizeof(T));
+        const long long skew = 256 / (long long)sizeof(T);
+        int rc = ensure_tmp(p, (size_t)(2 * vol_in + skew) * sizeof(T));
         if (rc) return rc;
         T* a = (T*)p->tmp;
-        T* dd = a + vol_in;
+        T* dd = a + vol_in + skew;
         T* outs_a[8] = {a};
         T* outs_d[8] = {dd};
         rc = fused3_run<T>(p, true, Lp, in, outs_a, p->dims[2], n_top_in, vol3, vol3, 1, s, 0, LLONG_MIN, 0, 0xFE);   // in[0] = approximation
@@ -621,13 +633,14 @@ static int synthesis_level(ndwt_plan* p, const T* const* in, T* out, long long s
 // band bookkeeping of nddwt.c:210,225-234 / nd_dwt_3D.m:178-186: level `lev` (1 = finest) stores its
 // 2^d-1 detail bands at [1 + (2^d-1)(level-lev), ...); the coarsest approximation is band 0.  Unlike
 // the reference there is no cat() copy (nd_dwt_3D.m:184) and no in-place overwrite of the input.
-template <typename T> static int dec_impl(ndwt_plan* p, const T* x, T* y, int level, hipStream_t s) {
+// bs: distance between consecutive bands of y in scalars (p->vol = the packed reference layout; larger = pitched)
+template <typename T> static int dec_impl(ndwt_plan* p, const T* x, T* y, long long bs, int level, hipStream_t s) {
     const int nb = 1 << p->ndim;
     const T* cur = x;
     for (int lev = 1; lev <= level; ++lev) {
         T* out[16];
         out[0] = (lev == level) ? y : (T*)p->approx[(lev - 1) & 1];
-        for (int b = 1; b < nb; ++b) out[b] = y + (long long)(1 + (nb - 1) * (level - lev) + (b - 1)) * p->vol;
+        for (int b = 1; b < nb; ++b) out[b] = y + (long long)(1 + (nb - 1) * (level - lev) + (b - 1)) * bs;
         int rc = analysis_level<T>(p, cur, out, level_stride(p, lev), false, s);
         if (rc) return rc;
         cur = out[0];
@@ -635,14 +648,14 @@ template <typename T> static int dec_impl(ndwt_plan* p, const T* x, T* y, int le
     return NDWT_OK;
 }
 
-template <typename T> static int rec_impl(ndwt_plan* p, const T* y, T* x, int level, hipStream_t s) {
+template <typename T> static int rec_impl(ndwt_plan* p, const T* y, long long bs, T* x, int level, hipStream_t s) {
     const int nb = 1 << p->ndim;
     const T* prev = y;   // band 0
     for (int ind = 1; ind <= level; ++ind) {
         const int lev = level - ind + 1;
         const T* in[16];
         in[0] = prev;
-        for (int b = 1; b < nb; ++b) in[b] = y + (long long)(1 + (nb - 1) * (level - lev) + (b - 1)) * p->vol;
+        for (int b = 1; b < nb; ++b) in[b] = y + (long long)(1 + (nb - 1) * (level - lev) + (b - 1)) * bs;
         T* dst = (lev == 1) ? x : (T*)p->approx[(ind - 1) & 1];
         int rc = synthesis_level<T>(p, in, dst, level_stride(p, lev), false, s);
         if (rc) return rc;
@@ -723,10 +736,18 @@ __global__ void __launch_bounds__(256) shrink_kernel(T* __restrict__ y, long lon
     }
 }
 
-template <typename T> static int shrink_impl(ndwt_plan* p, T* y, int level, double thr, int mode, hipStream_t s) {
+template <typename T> static int shrink_run(ndwt_plan* p, T* d, long long n, double thr, int mode, hipStream_t s);
+template <typename T> static int shrink_impl(ndwt_plan* p, T* y, long long bs, int level, double thr, int mode, hipStream_t s) {
     const long long nb = ndwt_num_bands(p->ndim, level);
-    T* d = y + p->vol;                                   // band 0 (coarsest approximation) is left as it is
-    const long long n = (nb - 1) * p->vol;
+    // band 0 (coarsest approximation) is left as it is; packed bands are one run, pitched ones a launch per band
+    if (bs == p->vol) return shrink_run<T>(p, y + p->vol, (nb - 1) * p->vol, thr, mode, s);
+    for (long long b = 1; b < nb; ++b) {
+        int rc = shrink_run<T>(p, y + b * bs, p->vol, thr, mode, s);
+        if (rc) return rc;
+    }
+    return NDWT_OK;
+}
+template <typename T> static int shrink_run(ndwt_plan* p, T* d, long long n, double thr, int mode, hipStream_t s) {
     const bool vec = aligned_vec4<T>(d) && n % 4 == 0;
     long long blocks = ((vec ? n / 4 : n / p->comp) + 255) / 256;
     const long long cap = (long long)p->num_cus * 16;
@@ -1019,24 +1040,46 @@ int ndwt_plan_describe(const ndwt_plan* p, char* buf, int buflen) {
     return NDWT_OK;
 }
 
-int ndwt_dec(ndwt_plan* p, const void* x, void* y, int level, void* stream) {
-    int rc = check_level(p, level);
-    if (rc) return rc;
-    if (!x || !y) return fail(NDWT_ERR_INVALID_ARG, "null data pointer");
-    HIP_TRY(hipSetDevice(p->device));
-    hipStream_t s = (hipStream_t)stream;
-    return p->dtype == NDWT_F32 ? dec_impl<float>(p, (const float*)x, (float*)y, level, s)
-                                : dec_impl<double>(p, (const double*)x, (double*)y, level, s);
+// band pitch in elements -> scalars; 0 = packed
+static int pitch_scalars(const ndwt_plan* p, int64_t band_pitch, long long* bs) {
+    *bs = band_pitch == 0 ? p->vol : (long long)band_pitch * p->comp;
+    if (*bs < p->vol) return fail(NDWT_ERR_INVALID_ARG, "band pitch %lld is smaller than a band (%lld elements)", (long long)band_pitch, p->vol / p->comp);
+    return NDWT_OK;
 }
 
-int ndwt_rec(ndwt_plan* p, const void* y, void* x, int level, void* stream) {
+int ndwt_dec_pitched(ndwt_plan* p, const void* x, void* y, int64_t band_pitch, int level, void* stream) {
     int rc = check_level(p, level);
     if (rc) return rc;
     if (!x || !y) return fail(NDWT_ERR_INVALID_ARG, "null data pointer");
+    long long bs = 0;
+    rc = pitch_scalars(p, band_pitch, &bs);
+    if (rc) return rc;
     HIP_TRY(hipSetDevice(p->device));
     hipStream_t s = (hipStream_t)stream;
-    return p->dtype == NDWT_F32 ? rec_impl<float>(p, (const float*)y, (float*)x, level, s)
-                                : rec_impl<double>(p, (const double*)y, (double*)x, level, s);
+    return p->dtype == NDWT_F32 ? dec_impl<float>(p, (const float*)x, (float*)y, bs, level, s)
+                                : dec_impl<double>(p, (const double*)x, (double*)y, bs, level, s);
+}
+
+int ndwt_rec_pitched(ndwt_plan* p, const void* y, int64_t band_pitch, void* x, int level, void* stream) {
+    int rc = check_level(p, level);
+    if (rc) return rc;
+    if (!x || !y) return fail(NDWT_ERR_INVALID_ARG, "null data pointer");
+    long long bs = 0;
+    rc = pitch_scalars(p, band_pitch, &bs);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(p->device));
+    hipStream_t s = (hipStream_t)stream;
+    return p->dtype == NDWT_F32 ? rec_impl<float>(p, (const float*)y, bs, (float*)x, level, s)
+                                : rec_impl<double>(p, (const double*)y, bs, (double*)x, level, s);
+}
+
+int ndwt_dec(ndwt_plan* p, const void* x, void* y, int level, void* stream) { return ndwt_dec_pitched(p, x, y, 0, level, stream); }
+int ndwt_rec(ndwt_plan* p, const void* y, void* x, int level, void* stream) { return ndwt_rec_pitched(p, y, 0, x, level, stream); }
+
+int64_t ndwt_band_pitch(const ndwt_plan* p) {
+    if (!p) return 0;
+    const long long skew = 256 / (long long)(p->esize * p->comp);   // 256 bytes, in elements
+    return p->vol / p->comp + (skew > 0 ? skew : 1);
 }
 
 static int host_roundtrip(ndwt_plan* p, bool inverse, const void* src, void* dst, int level) {
@@ -1084,13 +1127,19 @@ static int shrink_check(const ndwt_plan* p, int level, double thr, int mode) {
     return NDWT_OK;
 }
 
-int ndwt_shrink(ndwt_plan* p, void* y, int level, double threshold, int mode, void* stream) {
+int ndwt_shrink_pitched(ndwt_plan* p, void* y, int64_t band_pitch, int level, double threshold, int mode, void* stream) {
     int rc = shrink_check(p, level, threshold, mode);
     if (rc) return rc;
     if (!y) return fail(NDWT_ERR_INVALID_ARG, "null data pointer");
+    long long bs = 0;
+    rc = pitch_scalars(p, band_pitch, &bs);
+    if (rc) return rc;
     HIP_TRY(hipSetDevice(p->device));
-    return p->dtype == NDWT_F32 ? shrink_impl<float>(p, (float*)y, level, threshold, mode, (hipStream_t)stream)
-                                : shrink_impl<double>(p, (double*)y, level, threshold, mode, (hipStream_t)stream);
+    return p->dtype == NDWT_F32 ? shrink_impl<float>(p, (float*)y, bs, level, threshold, mode, (hipStream_t)stream)
+                                : shrink_impl<double>(p, (double*)y, bs, level, threshold, mode, (hipStream_t)stream);
+}
+int ndwt_shrink(ndwt_plan* p, void* y, int level, double threshold, int mode, void* stream) {
+    return ndwt_shrink_pitched(p, y, 0, level, threshold, mode, stream);
 }
 
 int ndwt_denoise(ndwt_plan* p, const void* x, void* out, int level, double threshold, int mode, void* stream) {
@@ -1098,7 +1147,9 @@ int ndwt_denoise(ndwt_plan* p, const void* x, void* out, int level, double thres
     if (rc) return rc;
     if (!x || !out) return fail(NDWT_ERR_INVALID_ARG, "null data pointer");
     HIP_TRY(hipSetDevice(p->device));
-    const size_t need = (size_t)p->vol * p->esize * (size_t)ndwt_num_bands(p->ndim, level);
+    // the scratch coefficients are pitched (ndwt_band_pitch): nobody else reads them
+    const int64_t pitch = ndwt_band_pitch(p);
+    const size_t need = (size_t)pitch * p->comp * p->esize * (size_t)ndwt_num_bands(p->ndim, level);
     if (need > p->coef_bytes) {
         if (p->coef) {
             HIP_TRY(hipDeviceSynchronize());
@@ -1110,19 +1161,19 @@ int ndwt_denoise(ndwt_plan* p, const void* x, void* out, int level, double thres
         if (e != hipSuccess) return fail(NDWT_ERR_ALLOC, "hipMalloc(%zu bytes) for the coefficient scratch failed: %s", need, hipGetErrorString(e));
         p->coef_bytes = need;
     }
-    rc = ndwt_dec(p, x, p->coef, level, stream);
+    rc = ndwt_dec_pitched(p, x, p->coef, pitch, level, stream);
     if (rc) return rc;
     if (fused_shrink_capable(p)) {
         // every level is reconstructed by a lane-shift kernel: the detail bands are thresholded in registers as that
         // kernel loads them, and the separate pass (a read and a write of every detail band) disappears
         p->shrink_mode = mode == NDWT_SHRINK_HARD ? 2 : 1;
         p->shrink_thr = threshold;
-        rc = ndwt_rec(p, p->coef, out, level, stream);
+        rc = ndwt_rec_pitched(p, p->coef, pitch, out, level, stream);
         p->shrink_mode = 0;
         return rc;
     }
-    rc = ndwt_shrink(p, p->coef, level, threshold, mode, stream);
-    if (rc == NDWT_OK) rc = ndwt_rec(p, p->coef, out, level, stream);
+    rc = ndwt_shrink_pitched(p, p->coef, pitch, level, threshold, mode, stream);
+    if (rc == NDWT_OK) rc = ndwt_rec_pitched(p, p->coef, pitch, out, level, stream);
     return rc;
 }
 

@@ -355,6 +355,48 @@ def test_shrink_and_denoise_against_numpy(d, sizes, wn, cplx, precision):
         w.denoise(xg, 2, -1.0)
 
 
+@pytest.mark.parametrize("d,sizes,wn,cplx,precision,pitch", [
+    (3, [64, 32, 16], "db4", False, "single", "auto"),            # fused 3-D float (pair-packed synthesis)
+    (3, [24, 18, 12], ["db2", "db4", "db1"], False, "double", "auto"),
+    (3, [20, 16, 9], ["db3", "db2", "db2"], True, "single", 20 * 16 * 9 + 3),   # odd pitch: bands off the 16-byte grid, scalar kernels
+    (2, [64, 48], "db4", True, "double", "auto"),
+    (2, [37, 21], ["db4", "db1"], False, "single", 37 * 21 + 5),
+    (1, [130], "db3", False, "double", "auto"),
+    (4, [16, 12, 10, 8], "db2", False, "single", "auto"),          # 16 bands; the t-axis temporaries are skewed too
+    (3, [32, 32, 32], "db9", False, "single", "auto"),             # per-axis synthesis
+])
+def test_pitched_coefficient_layout_gives_the_packed_results(d, sizes, wn, cplx, precision, pitch):
+    """ndwt_dec_pitched / ndwt_rec_pitched / ndwt_shrink_pitched (include/ndwt.h): band b at b * band_pitch elements.  The
+    values are those of the packed (reference) layout bit for bit; the classes hand out and take pitched tensors transparently."""
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal(sizes) + (1j * rng.standard_normal(sizes) if cplx else 0)
+    xg = _colmajor_gpu(x, precision)
+    wp = _cls(d)(wn, sizes, "pres_l2_norm", 1, "precision", precision)
+    wq = _cls(d)(wn, sizes, "pres_l2_norm", 1, "precision", precision, "band_pitch", pitch)
+    level = 2
+    yp, yq = wp.dec(xg, level), wq.dec(xg, level)
+    vol = int(np.prod(sizes))
+    assert yq.shape == yp.shape and yq.stride()[-1] > vol and yp.stride()[-1] == vol
+    assert torch.equal(yq, yp)                                         # same kernels, same values
+    wl = [wn] * d if isinstance(wn, str) else wn
+    assert _relerr(yq.cpu().numpy(), orc.spatial_dec(x, wl, level, 1)) <= TOL[precision]
+    xr = wq.rec(yq)                                                    # pitched tensor used where it lies
+    assert torch.equal(xr, wp.rec(yp)) and torch.equal(xr, wp.rec(yq)) and torch.equal(xr, wq.rec(yq.contiguous()))
+    assert _relerr(xr.cpu().numpy(), x) < 20 * TOL[precision]
+    for mode in ("soft", "hard"):
+        sq = wq.shrink(yq, 0.4, mode)
+        assert sq.stride() == yq.stride() and sq.data_ptr() != yq.data_ptr()
+        assert torch.equal(sq, wp.shrink(yp, 0.4, mode))
+    assert torch.equal(yq, yp)                                         # shrink() returned a copy
+    den, want = wq.denoise(xg, level, 0.4), wp.rec(wp.shrink(yp, 0.4))   # (denoise may shrink inside the synthesis kernel: rounding)
+    assert float((den - want).abs().max()) <= 20 * TOL[precision] * max(float(want.abs().max()), 1.0)
+    with pytest.raises(ValueError, match="smaller than a band"):
+        _cls(d)(wn, sizes, "precision", precision, "band_pitch", vol - 1).dec(xg, 1)
+    plan = list(wp._plans.values())[0]
+    with pytest.raises(ndwt.NdwtError, match="smaller than a band"):
+        plan.rec(yp.data_ptr(), xr.data_ptr(), level, 0, band_pitch=vol - 1)
+
+
 def test_properties_linearity_shift_adjoint():
     torch.manual_seed(0)
     sizes = [48, 36, 40]
