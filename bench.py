@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument("--generic", action="store_true", help="force the per-axis kernels (for comparison)")
     ap.add_argument("--band-pitch", default="packed", choices=["packed", "auto"],
                     help="layout of the coefficient buffer between dec and rec: packed = the reference's; auto = ndwt_band_pitch()")
+    ap.add_argument("--packed-only", action="store_true", help="skip the secondary pass with pitched coefficients (profiling runs: "
+                    "both passes launch the same kernels, which a kernel-stats average would mix)")
     ap.add_argument("--zchunk", type=int, default=0)
     ap.add_argument("--target-blocks", type=int, default=0)
     a = ap.parse_args()
@@ -260,7 +262,7 @@ def main():
     # the same step with the coefficient buffer pitched (include/ndwt.h: ndwt_dec_pitched): what a caller that owns the buffer
     # gets; reported beside the headline, which keeps the reference's packed layout
     pitched = None
-    if not sharded and a.band_pitch == "packed":
+    if not sharded and a.band_pitch == "packed" and not a.packed_only:
         lay["y"] = y = None
         lay["pitch"] = plan.band_pitch()
         lay["y"] = torch.empty(nbands * lay["pitch"], device=dev, dtype=torch.float32)
@@ -282,6 +284,13 @@ def main():
                    "whole_step_frac": round(step_bytes / (dtp / a.steps) / 1e9 / HBM_PEAK_GBS, 4),
                    "avg_launch_ms": {KERNEL_NAMES[k]: round(pp[k][0] / pp[k][1], 4) for k in pp if pp[k][1]},
                    "roundtrip_rel_l2": float(torch.linalg.vector_norm((r - x).double()) / torch.linalg.vector_norm(x.double()))}
+        try:
+            if d == 3 and sizes == [512, 512, 512] and a.wname == "db4" and level == 3 and not a.generic:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+                pitched["traffic"] = {k: tj["pitched"][k]["traffic_bytes"] for k in ("fused_synthesis", "fused_analysis")}
+                pitched["traffic_source"] = "profiles/r02_traffic.json"
+        except Exception:
+            pass
 
     shape = "x".join(str(n) for n in sizes)
     cube = f"{sizes[0]}^3" if d == 3 and len(set(sizes)) == 1 else shape
