@@ -63,6 +63,11 @@ struct ProfRec {
     hipEvent_t start, stop;
 };
 
+#ifdef NDWT_NO_APPROX_SKEW
+static constexpr size_t kApproxSkew = 0;
+#else
+static constexpr size_t kApproxSkew = 256;
+#endif
 struct ndwt_plan {
     int ndim;
     long long dims[NDWT_MAX_DIMS];
@@ -72,7 +77,8 @@ struct ndwt_plan {
     size_t esize;                      // bytes per scalar
     long long comp;                    // scalars per element (2 for interleaved complex)
     long long vol;                     // scalars per band
-    void* approx[2];                   // approximation ping-pong between levels
+    void* approx[2];                   // approximation ping-pong between levels: approx_base[i] + kApproxSkew bytes
+    void* approx_base[2];
     void* tmp;                         // temporaries of the per-axis path / 4-D split
     size_t tmp_bytes;
     int target_blocks;                 // fused-kernel grid sizing: 0 = one round of resident workgroups (per kernel), else as given
@@ -911,7 +917,10 @@ static int plan_create_impl(ndwt_plan** plan, int ndim, const int64_t* dims, lon
     }
     const int napprox = max_level >= 3 ? 2 : (max_level == 2 ? 1 : 0);
     for (int i = 0; i < napprox; ++i) {
-        hipError_t e = hipMalloc(&p->approx[i], (size_t)p->vol * p->esize);
+        // 256 B off the allocation's (power-of-two) alignment: the approximation is then the one band of a level that does not
+        // share the address bits below 1 KiB with the packed detail bands (about a quarter of the pitched gain)
+        hipError_t e = hipMalloc(&p->approx_base[i], (size_t)p->vol * p->esize + kApproxSkew);
+        if (e == hipSuccess) p->approx[i] = (char*)p->approx_base[i] + kApproxSkew;
         if (e != hipSuccess) {
             ndwt_plan_destroy(p);
             return fail(NDWT_ERR_ALLOC, "hipMalloc of the approximation scratch failed: %s", hipGetErrorString(e));
@@ -972,7 +981,7 @@ int ndwt_plan_destroy(ndwt_plan* p) {
     if (!p) return NDWT_OK;
     (void)hipSetDevice(p->device);
     for (int i = 0; i < 2; ++i)
-        if (p->approx[i]) (void)hipFree(p->approx[i]);
+        if (p->approx_base[i]) (void)hipFree(p->approx_base[i]);
     if (p->tmp) (void)hipFree(p->tmp);
     if (p->coef) (void)hipFree(p->coef);
     for (int i = 0; i < 2; ++i)
