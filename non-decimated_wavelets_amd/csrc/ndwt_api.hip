@@ -284,14 +284,16 @@ template <typename T> static int generic_synthesis(GenericCtx<T>& c, int axis, i
 
 // ------------------------------------------------------------------------------------ fused levels
 // dir: 0 analysis, 1 synthesis, -1 both.  Instantiated tap lengths: 2..12 (db1..db6) for every data kind the checks below let
-// through; float real data also 14, 16 (db7, db8) and, analysis only, 18 (db9).  Longer filters take the per-axis path.
+// through; float real data also 14, 16, 18 (db7 .. db9; 18-tap synthesis with the pair-packed kernel only).  db10 takes the per-axis path.
+static bool inv3y_plan_ok(const ndwt_plan* p, int Lp);
 static bool fused3_eligible(const ndwt_plan* p, long long stride, int* Lp_out, int dir = -1) {
     if (p->path != NDWT_PATH_AUTO || stride != 1 || p->ndim < 3) return false;
     if (p->dtype == NDWT_F64 && !p->fp64_fused) return false;
     int Lp = 2;
     for (int a = 0; a < 3; ++a) Lp = p->filt[a].len > Lp ? p->filt[a].len : Lp;
     const int lmax = (p->dtype == NDWT_F32 && p->complexity == NDWT_REAL) ? (dir == 0 ? 18 : 16) : 12;
-    if (Lp > lmax) return false;
+    // 18-tap synthesis exists as the pair-packed kernel only (uniform wavelets, or mixed ones with even padding on every axis)
+    if (Lp > lmax && !(dir == 1 && Lp == 18 && inv3y_plan_ok(p, Lp))) return false;
     if (p->dtype == NDWT_F64 && Lp > 10) return false;   // double, db6: the fused kernels spill (6.7 ms vs 4.8 ms per-axis at 256^3)
     // interleaved complex: the fused kernels with the x taps stepping over (re, im) pairs, tap lengths <= 8
     if (p->complexity != NDWT_REAL && (Lp > 8 || (p->dims[0] * 2) % 4 != 0)) return false;
@@ -376,6 +378,7 @@ void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int
         *TY = (variant == 3 && Lp == 8) ? 8 : 16;                                 // lane-shift kernel 64x16; variant 3 = LDS kernel
     } else {
         *TY = (variant == 3 && Lp == 8) ? 16 : (ew == 4 ? 16 : 32);              // tall tile; x taps over 4 scalars: 64x16 / 512 threads
+        if (ew == 1 && Lp > 16) *TY = inv3y_ty(Lp);                               // 18 taps: the pair-packed kernel's 64x24 tile
     }
 }
 }  // namespace ndwt
@@ -383,11 +386,14 @@ void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int
 // Float synthesis default: the pair-packed kernel.  It derives the high-pass taps from the low-pass ones (mirror + alternating
 // signs), which holds for the zero-padded taps of an axis when its padding (Lp - len) / 2 is even; it keeps plane offsets in
 // 32-bit BYTE counts.  variant_inv 4 forces the older lane-shift kernel (Inv3S) for A/B runs.
-template <typename T> static bool inv3y_eligible(const ndwt_plan* p, int Lp, const Fused3Args<T>& a) {
-    if (p->dtype != NDWT_F32 || p->comp != 1 || Lp > 12 || p->variant_inv == 3 || p->variant_inv == 4) return false;
+static bool inv3y_plan_ok(const ndwt_plan* p, int Lp) {
+    if (p->dtype != NDWT_F32 || p->comp != 1 || Lp > 18 || p->variant_inv == 3 || p->variant_inv == 4) return false;
     for (int ax = 0; ax < 3; ++ax)
         if (((Lp - p->filt[ax].len) / 2) % 2 != 0) return false;
-    return (long long)a.rs * a.n2 < (1LL << 30);
+    return p->dims[0] * p->dims[1] < (1LL << 30);
+}
+template <typename T> static bool inv3y_eligible(const ndwt_plan* p, int Lp, const Fused3Args<T>& a) {
+    return inv3y_plan_ok(p, Lp) && (long long)a.rs * a.n2 < (1LL << 30);
 }
 
 // one fused 3-D launch over `nbatch` volumes. n3 = output planes; z_wrap=false: inputs carry the z halo
@@ -1043,7 +1049,9 @@ int ndwt_plan_describe(const ndwt_plan* p, char* buf, int buflen) {
     if (!p || !buf || buflen < 1) return fail(NDWT_ERR_INVALID_ARG, "bad arguments");
     int Lp = 0;
     const char* s = "axis";
-    if (fused3_eligible(p, 1, &Lp)) s = p->ndim == 3 ? "fused3d" : "axis+fused3d";
+    const bool f3a = fused3_eligible(p, 1, &Lp, 0), f3s = fused3_eligible(p, 1, &Lp, 1);
+    if (f3a && f3s) s = p->ndim == 3 ? "fused3d" : "axis+fused3d";
+    else if (f3a) s = p->ndim == 3 ? "fused3d analysis, axis synthesis" : "axis+fused3d analysis, axis synthesis";
     else if (fused2_eligible(p, 1, &Lp)) s = "fused2d";
     snprintf(buf, (size_t)buflen, "%s", s);
     return NDWT_OK;

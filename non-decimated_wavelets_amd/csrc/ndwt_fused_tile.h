@@ -26,4 +26,6 @@ template <int V> struct Fused3Tile<double, true, V>  { static constexpr int TX =
 template <> struct Fused3Tile<double, true, 1>       { static constexpr int TX = 64, TY = 16, NT = 512, RY = 2, WPE = 2; };   // lane-shift kernel (Inv3S): the double default
 // float synthesis default (pair-packed kernel Inv3Y): 64 x 32 tile, 1024 threads, one workgroup per CU
 constexpr int kInv3YTX = 64, kInv3YTY = 32;
+// rows of the pair-packed synthesis tile: the haloed rows (TY + L - 1) must fit the 16 waves of the workgroup, three rows each
+constexpr int inv3y_ty(int L) { return L <= 16 ? kInv3YTY : 24; }
 }  // namespace ndwt

@@ -110,6 +110,10 @@ CASES_Y = [
     ((70, 60, 10), ("db2", "db2", "db4"), False, 6, False),
     ((24, 21, 13), ("db5", "db5", "db5"), True, 0, True),
     ((21, 14, 12), ("db5", "db3", "db1"), False, 5, True),
+    ((24, 23, 19), ("db7", "db7", "db7"), True, 0, True),
+    ((28, 20, 21), ("db8", "db8", "db4"), True, 7, True),
+    ((20, 26, 20), ("db9", "db9", "db9"), True, 0, True),         # 25 haloed rows: two rounds of rows on the small tile
+    ((23, 19, 18), ("db9", "db7", "db5"), False, 6, True),
     ((72, 37, 12), ("db6", "db6", "db6"), True, 0, False),       # production tile shape, 12 taps: 15 of the 16 waves hold rows
 ]
 

@@ -363,7 +363,7 @@ def test_shrink_and_denoise_against_numpy(d, sizes, wn, cplx, precision):
     (2, [37, 21], ["db4", "db1"], False, "single", 37 * 21 + 5),
     (1, [130], "db3", False, "double", "auto"),
     (4, [16, 12, 10, 8], "db2", False, "single", "auto"),          # 16 bands; the t-axis temporaries are skewed too
-    (3, [32, 32, 32], "db9", False, "single", "auto"),             # per-axis synthesis
+    (3, [32, 32, 32], ["db9", "db8", "db8"], False, "single", "auto"),   # fused analysis, per-axis synthesis (odd tap padding)
 ])
 def test_pitched_coefficient_layout_gives_the_packed_results(d, sizes, wn, cplx, precision, pitch):
     """ndwt_dec_pitched / ndwt_rec_pitched / ndwt_shrink_pitched (include/ndwt.h): band b at b * band_pitch elements.  The
@@ -395,6 +395,33 @@ def test_pitched_coefficient_layout_gives_the_packed_results(d, sizes, wn, cplx,
     plan = list(wp._plans.values())[0]
     with pytest.raises(ndwt.NdwtError, match="smaller than a band"):
         plan.rec(yp.data_ptr(), xr.data_ptr(), level, 0, band_pitch=vol - 1)
+
+
+@pytest.mark.parametrize("sizes,wn,path", [
+    ([64, 40, 36], "db7", "fused3d"),
+    ([68, 41, 30], "db8", "fused3d"),
+    ([64, 48, 32], "db9", "fused3d"),                                  # 18 taps: pair-packed synthesis on its 64 x 24 tile
+    ([70, 37, 33], "db9", "fused3d"),                                  # ... scalar accesses (n1 not a multiple of 4), ragged tiles
+    ([64, 40, 36], ["db9", "db7", "db5"], "fused3d"),                  # mixed wavelets, even padding to 18 taps on every axis
+    ([64, 40, 36], ["db9", "db8", "db8"], "fused3d analysis, axis synthesis"),   # odd padding: no derived high-pass taps
+    ([64, 40, 36], ["db8", "db7", "db7"], "fused3d"),                  # odd padding, 16 taps: the lane-shift kernel
+    ([64, 40, 36], "db10", "axis"),
+])
+def test_long_filters_float(sizes, wn, path):
+    """db7 .. db10 on real float data: which kernels serve them, and parity with the oracle for dec, rec and the round trip"""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(sizes)
+    w = ndwt.nd_dwt_3D(wn, sizes, "pres_l2_norm", 1, "precision", "single")
+    xg = _colmajor_gpu(x, "single")
+    y = w.dec(xg, 2)
+    assert list(w._plans.values())[0].describe() == path
+    wl = [wn] * 3 if isinstance(wn, str) else wn
+    assert _relerr(y.cpu().numpy(), orc.spatial_dec(x, wl, 2, 1)) <= TOL["single"]
+    c = rng.standard_normal(sizes + [15])
+    got = w.rec(_colmajor_gpu(c, "single")).cpu().numpy()
+    want = orc.spatial_rec(c, wl, 1)
+    assert np.abs(got - want).max() <= TOL["single"] * max(np.abs(want).max(), np.abs(c).max())
+    assert _relerr(w.rec(y).cpu().numpy(), x) < 1e-5
 
 
 def test_properties_linearity_shift_adjoint():
