@@ -284,16 +284,16 @@ template <typename T> static int generic_synthesis(GenericCtx<T>& c, int axis, i
 
 // ------------------------------------------------------------------------------------ fused levels
 // dir: 0 analysis, 1 synthesis, -1 both.  Instantiated tap lengths: 2..12 (db1..db6) for every data kind the checks below let
-// through; float real data also 14, 16, 18 (db7 .. db9; 18-tap synthesis with the pair-packed kernel only).  db10 takes the per-axis path.
+// through; float real data also 14 .. 20 (db7 .. db10; 18- and 20-tap synthesis with the pair-packed kernel only).
 static bool inv3y_plan_ok(const ndwt_plan* p, int Lp);
 static bool fused3_eligible(const ndwt_plan* p, long long stride, int* Lp_out, int dir = -1) {
     if (p->path != NDWT_PATH_AUTO || stride != 1 || p->ndim < 3) return false;
     if (p->dtype == NDWT_F64 && !p->fp64_fused) return false;
     int Lp = 2;
     for (int a = 0; a < 3; ++a) Lp = p->filt[a].len > Lp ? p->filt[a].len : Lp;
-    const int lmax = (p->dtype == NDWT_F32 && p->complexity == NDWT_REAL) ? (dir == 0 ? 18 : 16) : 12;
-    // 18-tap synthesis exists as the pair-packed kernel only (uniform wavelets, or mixed ones with even padding on every axis)
-    if (Lp > lmax && !(dir == 1 && Lp == 18 && inv3y_plan_ok(p, Lp))) return false;
+    const int lmax = (p->dtype == NDWT_F32 && p->complexity == NDWT_REAL) ? (dir == 0 ? 20 : 16) : 12;
+    // 18- and 20-tap synthesis exist as the pair-packed kernel only (uniform wavelets, or mixed ones with even padding on every axis)
+    if (Lp > lmax && !(dir == 1 && Lp <= 20 && inv3y_plan_ok(p, Lp))) return false;
     if (p->dtype == NDWT_F64 && Lp > 10) return false;   // double, db6: the fused kernels spill (6.7 ms vs 4.8 ms per-axis at 256^3)
     // interleaved complex: the fused kernels with the x taps stepping over (re, im) pairs, tap lengths <= 8
     if (p->complexity != NDWT_REAL && (Lp > 8 || (p->dims[0] * 2) % 4 != 0)) return false;
@@ -378,7 +378,7 @@ void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int
         *TY = (variant == 3 && Lp == 8) ? 8 : 16;                                 // lane-shift kernel 64x16; variant 3 = LDS kernel
     } else {
         *TY = (variant == 3 && Lp == 8) ? 16 : (ew == 4 ? 16 : 32);              // tall tile; x taps over 4 scalars: 64x16 / 512 threads
-        if (ew == 1 && Lp > 16) *TY = inv3y_ty(Lp);                               // 18 taps: the pair-packed kernel's 64x24 tile
+        if (ew == 1 && Lp > 16) { *TX = inv3y_tx(Lp); *TY = inv3y_ty(Lp); }       // 18 / 20 taps: the pair-packed kernel's 64x24 / 48x28 tile
     }
 }
 }  // namespace ndwt
@@ -387,7 +387,7 @@ void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int
 // signs), which holds for the zero-padded taps of an axis when its padding (Lp - len) / 2 is even; it keeps plane offsets in
 // 32-bit BYTE counts.  variant_inv 4 forces the older lane-shift kernel (Inv3S) for A/B runs.
 static bool inv3y_plan_ok(const ndwt_plan* p, int Lp) {
-    if (p->dtype != NDWT_F32 || p->comp != 1 || Lp > 18 || p->variant_inv == 3 || p->variant_inv == 4) return false;
+    if (p->dtype != NDWT_F32 || p->comp != 1 || Lp > 20 || p->variant_inv == 3 || p->variant_inv == 4) return false;
     for (int ax = 0; ax < 3; ++ax)
         if (((Lp - p->filt[ax].len) / 2) % 2 != 0) return false;
     return p->dims[0] * p->dims[1] < (1LL << 30);

@@ -1,9 +1,9 @@
-// fused 3-D inv level, float, real data, stride 1: the pair-packed lane-shift kernel (Inv3Y), tap lengths 2..18
+// fused 3-D inv level, float, real data, stride 1: the pair-packed lane-shift kernel (Inv3Y), tap lengths 2..20
 #include "ndwt_fused_kernels.h"
 namespace ndwt {
 
 template <int LL, bool V, int DEPTH> static int go(const Fused3Args<float>& a, const void* taps_dev, hipStream_t s) {
-    typedef Inv3Y<float, LL, kInv3YTX, inv3y_ty(LL), 1024, V, 4, DEPTH> K;
+    typedef Inv3Y<float, LL, inv3y_tx(LL), inv3y_ty(LL), 1024, V, 4, DEPTH> K;
     FusedTapsD unused;
     unused.Lp = LL;
     return launch_fused3<K>(a, unused, taps_dev, s);
@@ -31,6 +31,7 @@ int launch_inv3y_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, c
         NDWT_INVY_CASE(14, false)
         NDWT_INVY_CASE(16, false)
         NDWT_INVY_CASE(18, false)     // 64 x 24 tile: 41 haloed rows on 14 waves
+        NDWT_INVY_CASE(20, false)     // 48 x 28 tile: 47 haloed rows on 16 waves (3 spilled registers, reloaded once per plane)
 #endif
         default: return -1;
     }

@@ -1,6 +1,6 @@
-// fused 3-D levels, float, tap lengths 14 .. 18 (db7 .. db9): the 512-thread tiles with the 256-register budget
-// (analysis 64x16, one column per thread; synthesis 64x32, two items per thread).  db9 fits on the analysis side only and db10
-// on neither (the z window / the pending partial sums of 20 planes): those stay on the per-axis kernels.
+// fused 3-D levels, float, tap lengths 14 .. 20 (db7 .. db10): the 512-thread tiles with the 256-register budget
+// (analysis 64x16, one column per thread; synthesis 64x32, two items per thread: 14 and 16 taps only -- the fallback of the
+// pair-packed kernel for mixed wavelets with odd tap padding).
 #include "ndwt_fused_kernels.h"
 namespace ndwt {
 int launch_long3_f32(bool inverse, const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, const void* taps_dev, hipStream_t s) {
@@ -9,6 +9,7 @@ int launch_long3_f32(bool inverse, const Fused3Args<float>& a, const FusedTapsD&
             NDWT_FUSED_CASE(Fwd3, false, float, 14, 1)
             NDWT_FUSED_CASE(Fwd3, false, float, 16, 1)
             NDWT_FUSED_CASE(Fwd3, false, float, 18, 1)
+            NDWT_FUSED_CASE(Fwd3, false, float, 20, 1)   // spills 18 of its 256 registers; still 5x the per-axis path
             default: return -1;
         }
     }

@@ -27,5 +27,7 @@ template <> struct Fused3Tile<double, true, 1>       { static constexpr int TX =
 // float synthesis default (pair-packed kernel Inv3Y): 64 x 32 tile, 1024 threads, one workgroup per CU
 constexpr int kInv3YTX = 64, kInv3YTY = 32;
 // rows of the pair-packed synthesis tile: the haloed rows (TY + L - 1) must fit the 16 waves of the workgroup, three rows each
-constexpr int inv3y_ty(int L) { return L <= 16 ? kInv3YTY : 24; }
+constexpr int inv3y_ty(int L) { return L <= 16 ? kInv3YTY : (L <= 18 ? 24 : 28); }
+// 20 taps: 22 lanes per haloed row of a 64-wide tile leave two rows per wave; 48 wide = 18 lanes, three rows
+constexpr int inv3y_tx(int L) { return L <= 18 ? kInv3YTX : 48; }
 }  // namespace ndwt

@@ -81,7 +81,7 @@ int dispatchY(int Lp, int vec4, ndwt::Fused3Args<T>& a, const double* lo, const 
                     : runY<ndwt::Inv3Y<T, LL, TX, TY, NT, false, 2, DEPTH>, T>(a, lo, hi);
     if constexpr (ALL) {
         switch (Lp) {
-            CASEY(2) CASEY(4) CASEY(6) CASEY(8) CASEY(10) CASEY(12) CASEY(14) CASEY(16) CASEY(18)
+            CASEY(2) CASEY(4) CASEY(6) CASEY(8) CASEY(10) CASEY(12) CASEY(14) CASEY(16) CASEY(18) CASEY(20)
             default: return -1;
         }
     } else {

@@ -114,6 +114,8 @@ CASES_Y = [
     ((28, 20, 21), ("db8", "db8", "db4"), True, 7, True),
     ((20, 26, 20), ("db9", "db9", "db9"), True, 0, True),         # 25 haloed rows: two rounds of rows on the small tile
     ((23, 19, 18), ("db9", "db7", "db5"), False, 6, True),
+    ((24, 22, 21), ("db10", "db10", "db10"), True, 0, True),      # 27 haloed rows: three rounds of rows on the small tile
+    ((21, 20, 20), ("db10", "db8", "db6"), False, 4, True),
     ((72, 37, 12), ("db6", "db6", "db6"), True, 0, False),       # production tile shape, 12 taps: 15 of the 16 waves hold rows
 ]
 

@@ -405,7 +405,10 @@ def test_pitched_coefficient_layout_gives_the_packed_results(d, sizes, wn, cplx,
     ([64, 40, 36], ["db9", "db7", "db5"], "fused3d"),                  # mixed wavelets, even padding to 18 taps on every axis
     ([64, 40, 36], ["db9", "db8", "db8"], "fused3d analysis, axis synthesis"),   # odd padding: no derived high-pass taps
     ([64, 40, 36], ["db8", "db7", "db7"], "fused3d"),                  # odd padding, 16 taps: the lane-shift kernel
-    ([64, 40, 36], "db10", "axis"),
+    ([64, 40, 36], "db10", "fused3d"),                                 # 20 taps: 48 x 28 synthesis tile
+    ([100, 37, 33], "db10", "fused3d"),                                # ... ragged 48-wide tiles, rows and planes
+    ([62, 40, 36], ["db10", "db8", "db6"], "fused3d"),
+    ([64, 40, 36], ["db10", "db9", "db9"], "fused3d analysis, axis synthesis"),
 ])
 def test_long_filters_float(sizes, wn, path):
     """db7 .. db10 on real float data: which kernels serve them, and parity with the oracle for dec, rec and the round trip"""
