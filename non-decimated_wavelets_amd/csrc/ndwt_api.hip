@@ -295,8 +295,8 @@ static bool fused3_eligible(const ndwt_plan* p, long long stride, int* Lp_out, i
     // 18- and 20-tap synthesis exist as the pair-packed kernel only (uniform wavelets, or mixed ones with even padding on every axis)
     if (Lp > lmax && !(dir == 1 && Lp <= 20 && inv3y_plan_ok(p, Lp))) return false;
     if (p->dtype == NDWT_F64 && Lp > 10) return false;   // double, db6: the fused kernels spill (6.7 ms vs 4.8 ms per-axis at 256^3)
-    // interleaved complex: the fused kernels with the x taps stepping over (re, im) pairs, tap lengths <= 8
-    if (p->complexity != NDWT_REAL && (Lp > 8 || (p->dims[0] * 2) % 4 != 0)) return false;
+    // interleaved complex: the fused kernels with the x taps stepping over (re, im) pairs, tap lengths <= 8 (float: <= 12)
+    if (p->complexity != NDWT_REAL && (Lp > (p->dtype == NDWT_F32 ? 12 : 8) || (p->dims[0] * 2) % 4 != 0)) return false;
     long long nbatch = p->ndim == 4 ? p->dims[3] + 64 : 1;
     if (!fused3_fits(p->dims[0] * p->comp, p->dims[1], p->dims[2] + 64, nbatch)) return false;
     *Lp_out = Lp;

@@ -125,6 +125,8 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
             NDWT_FUSED_CASE_C(Inv3S, true, T, 4, 1)                       \
             NDWT_FUSED_CASE_C(Inv3S, true, T, 6, 1)                       \
             NDWT_FUSED_CASE_C(Inv3S, true, T, 8, 1)                       \
+            NDWT_FUSED_CASE_C(Inv3S, true, T, 10, 2)   /* complex db5 / db6: 512 threads x 2 items (db6 spills 42 of 256 registers) */ \
+            NDWT_FUSED_CASE_C(Inv3S, true, T, 12, 2)                      \
             default: return -1;                                           \
         }                                                                 \
     }                                                                     \
@@ -179,6 +181,8 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
             NDWT_FUSED_CASE_C(Fwd3, false, T, 4, 0)                       \
             NDWT_FUSED_CASE_C(Fwd3, false, T, 6, 0)                       \
             NDWT_FUSED_CASE_C(Fwd3, false, T, 8, 0)                       \
+            NDWT_FUSED_CASE_C(Fwd3, false, T, 10, 1)                      \
+            NDWT_FUSED_CASE_C(Fwd3, false, T, 12, 1)                      \
             default: return -1;                                           \
         }                                                                 \
     }                                                                     \

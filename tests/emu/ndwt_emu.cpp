@@ -101,7 +101,7 @@ int dispatch(int Lp, int vec4, ndwt::Fused3Args<T>& a, const double* lo, const d
                     : run<KIND<T, LL, TX, TY, NT, RY, false, 2, EW>, T>(a, lo, hi);
     if constexpr (ALL) {
         switch (Lp) {
-            CASE(2) CASE(4) CASE(6) CASE(8) CASE(12)
+            CASE(2) CASE(4) CASE(6) CASE(8) CASE(10) CASE(12)
             default: return -1;
         }
     } else {   // the production tile shape is emulated for db4 only (build time)

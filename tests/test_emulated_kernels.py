@@ -280,6 +280,8 @@ CPLX3 = [
     ((10, 9, 7), ("db1", "db3", "db2"), False, 0, True),
     ((24, 17, 12), ("db4", "db4", "db4"), True, 5, True),
     ((70, 19, 10), ("db4", "db2", "db4"), True, 6, False),     # production tiles (analysis 64x16, synthesis 64x32)
+    ((22, 15, 13), ("db5", "db5", "db5"), True, 0, True),      # 10 / 12 taps over (re, im) pairs: 5- and 6-group halos
+    ((26, 14, 12), ("db6", "db3", "db6"), True, 5, True),
 ]
 
 

@@ -427,6 +427,30 @@ def test_long_filters_float(sizes, wn, path):
     assert _relerr(w.rec(y).cpu().numpy(), x) < 1e-5
 
 
+@pytest.mark.parametrize("sizes,wn,precision,path", [
+    ([32, 24, 20], "db5", "single", "fused3d"),
+    ([34, 21, 19], "db6", "single", "fused3d"),
+    ([32, 24, 20], ["db6", "db2", "db5"], "single", "fused3d"),
+    ([32, 24, 20], "db7", "single", "axis"),
+    ([32, 24, 20], "db5", "double", "axis"),                           # complex128: fused up to 8 taps
+])
+def test_long_filters_complex(sizes, wn, precision, path):
+    """interleaved complex data with 10 / 12 taps: fused in single precision (x taps step over (re, im) pairs)"""
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal(sizes) + 1j * rng.standard_normal(sizes)
+    w = ndwt.nd_dwt_3D(wn, sizes, "pres_l2_norm", 1, "precision", precision)
+    xg = _colmajor_gpu(x, precision)
+    y = w.dec(xg, 2)
+    assert list(w._plans.values())[0].describe() == path
+    wl = [wn] * 3 if isinstance(wn, str) else wn
+    assert _relerr(y.cpu().numpy(), orc.spatial_dec(x, wl, 2, 1)) <= TOL[precision]
+    c = rng.standard_normal(sizes + [15]) + 1j * rng.standard_normal(sizes + [15])
+    got = w.rec(_colmajor_gpu(c, precision)).cpu().numpy()
+    want = orc.spatial_rec(c, wl, 1)
+    assert np.abs(got - want).max() <= TOL[precision] * max(np.abs(want).max(), np.abs(c).max())
+    assert _relerr(w.rec(y).cpu().numpy(), x) < 20 * TOL[precision]
+
+
 def test_properties_linearity_shift_adjoint():
     torch.manual_seed(0)
     sizes = [48, 36, 40]
