@@ -378,7 +378,6 @@ void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int
         *TY = (variant == 3 && Lp == 8) ? 8 : 16;                                 // lane-shift kernel 64x16; variant 3 = LDS kernel
     } else {
         *TY = (variant == 3 && Lp == 8) ? 16 : (ew == 4 ? 16 : 32);              // tall tile; x taps over 4 scalars: 64x16 / 512 threads
-        if (ew == 1 && Lp > 16) { *TX = inv3y_tx(Lp); *TY = inv3y_ty(Lp); }       // 18 / 20 taps: the pair-packed kernel's 64x24 / 48x28 tile
     }
 }
 }  // namespace ndwt
@@ -387,13 +386,10 @@ void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int
 // signs), which holds for the zero-padded taps of an axis when its padding (Lp - len) / 2 is even; it keeps plane offsets in
 // 32-bit BYTE counts.  variant_inv 4 forces the older lane-shift kernel (Inv3S) for A/B runs.
 static bool inv3y_plan_ok(const ndwt_plan* p, int Lp) {
-    if (p->dtype != NDWT_F32 || p->comp != 1 || Lp > 20 || p->variant_inv == 3 || p->variant_inv == 4) return false;
+    if (p->dtype != NDWT_F32 || Lp > (p->comp == 1 ? 20 : 12) || p->variant_inv == 3 || p->variant_inv == 4) return false;
     for (int ax = 0; ax < 3; ++ax)
         if (((Lp - p->filt[ax].len) / 2) % 2 != 0) return false;
-    return p->dims[0] * p->dims[1] < (1LL << 30);
-}
-template <typename T> static bool inv3y_eligible(const ndwt_plan* p, int Lp, const Fused3Args<T>& a) {
-    return inv3y_plan_ok(p, Lp) && (long long)a.rs * a.n2 < (1LL << 30);
+    return p->dims[0] * p->comp * p->dims[1] < (1LL << 30);
 }
 
 // one fused 3-D launch over `nbatch` volumes. n3 = output planes; z_wrap=false: inputs carry the z halo
@@ -436,6 +432,11 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     const int variant = inverse ? p->variant_inv : p->variant_fwd;
     const int ew = dil > 1 ? dil : (int)p->comp;
     fused3_tile_shape(sizeof(T) == 8, inverse, ew != 1 ? 0 : variant, Lp, &TX, &TY, ew);
+    bool use_y = false;                                   // float synthesis default: the pair-packed kernel and its tile
+    if constexpr (sizeof(T) == 4) {
+        use_y = inverse && dil == 1 && inv3y_plan_ok(p, Lp);   // (plane offsets stay below 2^32 bytes: checked there)
+        if (use_y) { TX = ndwt::inv3y_tx(Lp, ew); TY = ndwt::inv3y_ty(Lp, ew); }
+    }
     const int zc_force = p->zchunk_dir[inverse ? 1 : 0] > 0 ? p->zchunk_dir[inverse ? 1 : 0] : p->force_zchunk;
     // One round of workgroups that all fit on the chip at once beats several partial rounds (measured, 512^3 float
     // analysis: 512 workgroups 0.88 ms, 1024: 1.09 ms, 2048: 0.99 ms; 256^3 double synthesis: 256 workgroups 0.36 ms,
@@ -459,7 +460,7 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     prof_begin(p, inverse ? NDWT_KERNEL_FUSED_SYNTHESIS : NDWT_KERNEL_FUSED_ANALYSIS, s);
     int rc = -1;
     if constexpr (sizeof(T) == 4) {
-        if (inverse && dil == 1 && inv3y_eligible(p, Lp, a)) rc = launch_inv3y_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s);
+        if (use_y) rc = ew == 2 ? launch_inv3yc_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s) : launch_inv3y_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s);
     }
     if constexpr (sizeof(T) == 4) {
         if (rc == -1 && Lp > 12 && ew == 1) rc = launch_long3_f32(inverse, a, t, vec4, td, s);

@@ -1091,22 +1091,25 @@ template <typename T, int L> struct Taps3Y {             // the first two member
     T xphi[L + 1][2];        // the same for the high-pass taps (not read by Inv3Y, which derives them)
 };
 
-template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 4, int DEPTH_ = 1> struct Inv3Y {
+// EW = 2: interleaved complex data.  A pair of adjacent scalars is then the (re, im) of one element and takes ONE tap, so the x
+// stage has the form of the y and z stages (a broadcast tap per packed FMA) and the (t[k], t[k-1]) tap pairs are not used.
+template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 4, int DEPTH_ = 1, int EW_ = 1> struct Inv3Y {
     static_assert(sizeof(T) == 4, "pair-packed synthesis: float only (v_pk_fma_f32)");
-    static constexpr int L = L_, TX = TX_, TY = TY_, NT = NT_, WPE = WPE_, EW = 1;
+    static_assert(EW_ == 1 || EW_ == 2, "real or interleaved complex data");
+    static constexpr int L = L_, TX = TX_, TY = TY_, NT = NT_, WPE = WPE_, EW = EW_;
     static constexpr bool VEC4 = VEC4_;
     static constexpr int DEPTH = DEPTH_;                 // register sets of band loads per lane (planes in flight)
     static_assert(DEPTH == 1 || DEPTH == 2, "one or two register sets");
     static constexpr int NE = VEC4 ? 1 : 4;
     static constexpr int LH = L / 2, RH = L / 2 - 1;
-    static constexpr int GL = (LH + 3) / 4, GR = (RH + 3) / 4;
+    static constexpr int GL = (LH * EW + 3) / 4, GR = (RH * EW + 3) / 4;
     static constexpr int NG = TX / 4 + GL + GR;          // lanes per haloed row
     static constexpr int NR = TY + L - 1;                // haloed rows: loaded, x-synthesised, kept in LDS
     static constexpr int RPW = 64 / NG;                  // rows per wave
     static constexpr int NW = NT / 64;
     static constexpr int RPR = RPW * NW;                 // rows per round
     static constexpr int NRND = (NR + RPR - 1) / RPR;
-    static constexpr int TXC = TX / 2;                   // chunks per row: one 16-byte chunk = two adjacent x
+    static constexpr int TXC = TX / 2;                   // chunks per row: one 16-byte chunk = two adjacent x (EW = 2: one element)
     static constexpr int YITEMS = TXC * TY;              // y/z item: one chunk column of one output row
     static constexpr int NYI = (YITEMS + NT - 1) / NT;
     static constexpr int XV = 4 * (1 + GL + GR);
@@ -1137,8 +1140,9 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
     // operand modifiers of the packed FMAs).  Passed through an empty asm so that the compiler treats them as values to keep
     // in registers: as loads from constant memory it re-issues them (s_load + lgkmcnt(0)) inside every band of the x stage.
     struct RegTaps {
-        v2 xp[L + 1];              // (lo_x[k], lo_x[k-1])
-        v2 yl[L / 2], zl[L / 2];   // (lo[2m], lo[2m+1]) of the y and z axes
+        v2 xp[EW == 1 ? L + 1 : 1];   // (lo_x[k], lo_x[k-1]); real data only
+        v2 xl[EW == 2 ? L / 2 : 1];   // (lo_x[2m], lo_x[2m+1]); complex data only
+        v2 yl[L / 2], zl[L / 2];      // (lo[2m], lo[2m+1]) of the y and z axes
     };
     static NDWT_DEV v2 pinned(v2 t) {
 #ifndef NDWT_HOST_EMU
@@ -1147,9 +1151,15 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
         return t;
     }
     static NDWT_DEV void load_taps(RegTaps& rt, const Taps& tp) {
-        NDWT_SFOR(k, L + 1)
-            rt.xp[k] = pinned(v2{tp.xplo[k][0], tp.xplo[k][1]});
-        NDWT_SEND
+        if constexpr (EW == 1) {
+            NDWT_SFOR(k, L + 1)
+                rt.xp[k] = pinned(v2{tp.xplo[k][0], tp.xplo[k][1]});
+            NDWT_SEND
+        } else {
+            NDWT_SFOR(m, L / 2)
+                rt.xl[m] = pinned(v2{tp.lo[0][2 * m], tp.lo[0][2 * m + 1]});
+            NDWT_SEND
+        }
         NDWT_SFOR(m, L / 2)
             rt.yl[m] = pinned(v2{tp.lo[1][2 * m], tp.lo[1][2 * m + 1]});
             rt.zl[m] = pinned(v2{tp.lo[2][2 * m], tp.lo[2][2 * m + 1]});
@@ -1308,7 +1318,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
         if (a.shrink_mask == 0) return;
         NDWT_SFOR(k, NRND)
             NDWT_SFOR(b, 8)
-                if ((a.shrink_mask >> b) & 1) shrink4<T, 1>(st.raw[SET][k][b], a.shrink_thr, a.shrink_hard);
+                if ((a.shrink_mask >> b) & 1) shrink4<T, EW>(st.raw[SET][k][b], a.shrink_thr, a.shrink_hard);
             NDWT_SEND
         NDWT_SEND
     }
@@ -1336,13 +1346,21 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
                             constexpr int ka = 2 * m + KB, kb = 2 * m + 1 + KB;        // tap-pair index of entry 2m / 2m+1 for outputs (0,1)
                             constexpr bool ua01 = ka >= 0 && ka <= L, ub01 = kb >= 0 && kb <= L;
                             constexpr bool ua23 = ka - 2 >= 0 && ka - 2 <= L, ub23 = kb - 2 >= 0 && kb - 2 <= L;
-                            if constexpr (ua01 || ub01 || ua23 || ub23) {
+                            constexpr int jc0 = m - 2 * GL + LH, jc1 = jc0 - 1;             // EW = 2: taps of the lane's two elements
+                            constexpr bool c0ok = jc0 >= 0 && jc0 < L, c1ok = jc1 >= 0 && jc1 < L;
+                            if constexpr (EW == 1 ? (ua01 || ub01 || ua23 || ub23) : (c0ok || c1ok)) {
                                 const v2 w = {NDWT_LANE_SHIFT(ex, tid, D, s.raw[SET][k][xb + 2 * yb + 4 * zb][c]),
                                               NDWT_LANE_SHIFT(ex, tid, D, s.raw[SET][k][xb + 2 * yb + 4 * zb][c + 1])};
-                                if constexpr (ua01) xtap<0, ka, xb == 1>(acc[zb][0], w, tp);
-                                if constexpr (ub01) xtap<1, kb, xb == 1>(acc[zb][0], w, tp);
-                                if constexpr (ua23) xtap<0, ka - 2, xb == 1>(acc[zb][1], w, tp);
-                                if constexpr (ub23) xtap<1, kb - 2, xb == 1>(acc[zb][1], w, tp);
+                                if constexpr (EW == 1) {
+                                    if constexpr (ua01) xtap<0, ka, xb == 1>(acc[zb][0], w, tp);
+                                    if constexpr (ub01) xtap<1, kb, xb == 1>(acc[zb][0], w, tp);
+                                    if constexpr (ua23) xtap<0, ka - 2, xb == 1>(acc[zb][1], w, tp);
+                                    if constexpr (ub23) xtap<1, kb - 2, xb == 1>(acc[zb][1], w, tp);
+                                } else {
+                                    // w = window element m - 2 GL (re, im); it feeds the lane's element e through tap m - 2 GL - e + LH
+                                    if constexpr (c0ok) tap_fma<jc0 < 0 ? 0 : (jc0 >= L ? 0 : jc0), xb == 1>(acc[zb][0], w, tp.xl);
+                                    if constexpr (c1ok) tap_fma<jc1 < 0 ? 0 : (jc1 >= L ? 0 : jc1), xb == 1>(acc[zb][1], w, tp.xl);
+                                }
                             }
                         NDWT_SEND
                         NDWT_SCHED_FENCE();               // hipcc otherwise hoists every DPP move of a y-bit ahead of the FMAs

@@ -26,6 +26,7 @@ int launch_inv3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4,
 // float synthesis of real data with tap stride 1, tap lengths <= 8: the pair-packed kernel (Inv3Y) on a 64 x 32 tile with 1024
 // threads; depth = register sets of band loads (2: staggered refill, aligned volumes only)
 int launch_inv3y_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, const void* taps_dev, hipStream_t s);
+int launch_inv3yc_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, const void* taps_dev, hipStream_t s);   // interleaved complex
 
 // float, tap lengths 14..18 (analysis) / 14..16 (synthesis): ndwt_fused3_f32_long.hip
 int launch_long3_f32(bool inverse, const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, const void* taps_dev, hipStream_t s);

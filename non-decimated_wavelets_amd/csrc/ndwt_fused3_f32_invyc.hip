@@ -1,0 +1,31 @@
+// fused 3-D inv level, float, interleaved complex data, stride 1: the pair-packed lane-shift kernel (Inv3Y, EW = 2), tap lengths 2..12
+#include "ndwt_fused_kernels.h"
+namespace ndwt {
+
+template <int LL, bool V, int DEPTH> static int go(const Fused3Args<float>& a, const void* taps_dev, hipStream_t s) {
+    typedef Inv3Y<float, LL, inv3y_tx(LL, 2), inv3y_ty(LL, 2), 1024, V, 4, DEPTH, 2> K;
+    FusedTapsD unused;
+    unused.Lp = LL;
+    return launch_fused3<K>(a, unused, taps_dev, s);
+}
+
+// depth 2 (two register sets of band loads) where it fits 128 registers without spills, as for real data
+#define NDWT_INVYC_CASE(LL, D2OK) \
+    case LL:                      \
+        if constexpr (D2OK) {     \
+            if (vec4 && depth == 2) return go<LL, true, 2>(a, taps_dev, s); \
+        }                         \
+        return vec4 ? go<LL, true, 1>(a, taps_dev, s) : go<LL, false, 1>(a, taps_dev, s);
+
+int launch_inv3yc_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, const void* taps_dev, hipStream_t s) {
+    switch (Lp) {
+        NDWT_INVYC_CASE(2, true)
+        NDWT_INVYC_CASE(4, false)
+        NDWT_INVYC_CASE(6, false)
+        NDWT_INVYC_CASE(8, true)
+        NDWT_INVYC_CASE(10, true)
+        NDWT_INVYC_CASE(12, false)
+        default: return -1;
+    }
+}
+}  // namespace ndwt

@@ -26,8 +26,9 @@ template <int V> struct Fused3Tile<double, true, V>  { static constexpr int TX =
 template <> struct Fused3Tile<double, true, 1>       { static constexpr int TX = 64, TY = 16, NT = 512, RY = 2, WPE = 2; };   // lane-shift kernel (Inv3S): the double default
 // float synthesis default (pair-packed kernel Inv3Y): 64 x 32 tile, 1024 threads, one workgroup per CU
 constexpr int kInv3YTX = 64, kInv3YTY = 32;
-// rows of the pair-packed synthesis tile: the haloed rows (TY + L - 1) must fit the 16 waves of the workgroup, three rows each
-constexpr int inv3y_ty(int L) { return L <= 16 ? kInv3YTY : (L <= 18 ? 24 : 28); }
-// 20 taps: 22 lanes per haloed row of a 64-wide tile leave two rows per wave; 48 wide = 18 lanes, three rows
-constexpr int inv3y_tx(int L) { return L <= 18 ? kInv3YTX : 48; }
+// The pair-packed synthesis tile: the haloed rows (TY + L - 1) must fit the 16 waves of the workgroup at three rows per wave,
+// i.e. at most 21 lanes per haloed row.  Real data: 64 wide up to 18 taps (64x32, 18 taps 64x24), 20 taps 48x28 (22 lanes per
+// haloed 64-wide row would leave two rows per wave).  Interleaved complex (ew = 2, TX in scalars): 64 wide up to 10 taps, 12 taps 48.
+constexpr int inv3y_ty(int L, int ew = 1) { return ew == 2 ? kInv3YTY : (L <= 16 ? kInv3YTY : (L <= 18 ? 24 : 28)); }
+constexpr int inv3y_tx(int L, int ew = 1) { return ew == 2 ? (L <= 10 ? kInv3YTX : 48) : (L <= 18 ? kInv3YTX : 48); }
 }  // namespace ndwt

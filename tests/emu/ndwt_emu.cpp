@@ -73,12 +73,12 @@ int runY(ndwt::Fused3Args<T>& a, const double* lo, const double* hi) {
     return 0;
 }
 
-template <typename T, int TX, int TY, int NT, bool ALL, int DEPTH>
+template <typename T, int TX, int TY, int NT, bool ALL, int DEPTH, int EW = 1>
 int dispatchY(int Lp, int vec4, ndwt::Fused3Args<T>& a, const double* lo, const double* hi) {
 #define CASEY(LL)                                                                   \
     case LL:                                                                        \
-        return vec4 ? runY<ndwt::Inv3Y<T, LL, TX, TY, NT, true, 2, DEPTH>, T>(a, lo, hi)  \
-                    : runY<ndwt::Inv3Y<T, LL, TX, TY, NT, false, 2, DEPTH>, T>(a, lo, hi);
+        return vec4 ? runY<ndwt::Inv3Y<T, LL, TX, TY, NT, true, 2, DEPTH, EW>, T>(a, lo, hi)  \
+                    : runY<ndwt::Inv3Y<T, LL, TX, TY, NT, false, 2, DEPTH, EW>, T>(a, lo, hi);
     if constexpr (ALL) {
         switch (Lp) {
             CASEY(2) CASEY(4) CASEY(6) CASEY(8) CASEY(10) CASEY(12) CASEY(14) CASEY(16) CASEY(18) CASEY(20)
@@ -172,6 +172,13 @@ int emu3(int Lp, int vec4, const T* in, T* out, int n1, int n2, int n3, int nbat
         return -1;
     }
     if (ew == 2) {      // interleaved complex: n1 counts scalars; lane-shift synthesis and LDS analysis kernels
+        if constexpr (INV && sizeof(T) == 4) {   // pair-packed synthesis on (re, im) pairs: small tile, every tap length up to 12
+            if ((variant == 5 || variant == 8) && small_tile && Lp <= 12) {
+                geometry(16, 8);
+                return variant == 5 ? dispatchY<T, 16, 8, 128, true, 1, 2>(Lp, vec4, a, lo, hi)
+                                    : dispatchY<T, 16, 8, 512, true, 2, 2>(Lp, vec4, a, lo, hi);
+            }
+        }
         if (small_tile) {
             geometry(16, 8);
             if constexpr (INV) return dispatch<T, ndwt::Inv3S, 16, 8, 128, 2, true, 2>(Lp, vec4, a, lo, hi);

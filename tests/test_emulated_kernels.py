@@ -136,6 +136,31 @@ def test_emulated_pair_packed_synthesis(emu, sizes, wn, vec4, zchunk, small, l2)
         assert np.abs(got - want).max() <= 2e-6 * max(np.abs(want).max(), 1.0), variant
 
 
+CASES_YC = [
+    ((10, 9, 7), ("db1", "db3", "db1"), True, 0),
+    ((12, 10, 9), ("db2", "db2", "db2"), False, 4),
+    ((14, 17, 12), ("db4", "db4", "db4"), True, 5),
+    ((18, 13, 11), ("db5", "db3", "db1"), True, 0),
+    ((20, 15, 13), ("db6", "db6", "db6"), True, 6),              # 6 halo groups of two elements each
+    ((13, 12, 12), ("db6", "db2", "db4"), False, 0),
+]
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("sizes,wn,vec4,zchunk", CASES_YC)
+@pytest.mark.parametrize("l2", [0, 1])
+def test_emulated_pair_packed_synthesis_complex(emu, sizes, wn, vec4, zchunk, l2):
+    """Inv3Y on interleaved complex data (EW = 2): a pair is the (re, im) of one element and takes one tap"""
+    rng = np.random.default_rng(13)
+    c = rng.standard_normal(tuple(sizes) + (8,)) + 1j * rng.standard_normal(tuple(sizes) + (8,))
+    filt = [orc.wave_filters(w) for w in wn]
+    want = orc.spatial_level_rec(c, filt, l2)
+    for variant in ((5, 8) if vec4 else (5,)):
+        got = _run(emu, c, wn, l2, True, np.float32, vec4, zchunk, True, variant=variant, cplx=True)
+        assert np.isfinite(got).all(), variant
+        assert np.abs(got - want).max() <= 2e-6 * max(np.abs(want).max(), 1.0), variant
+
+
 def _run2(emu, arr, wnames, l2, inverse, dtype, vec4, ychunk, cplx=False, shrink=(0.0, 0, 0), dil=1):
     Ls = [len(orc.wave_filters(w)[0]) for w in wnames]
     Lp = max(Ls)
