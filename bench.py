@@ -301,7 +301,8 @@ def main():
                       "sharding": "none" if world == 1 else f"outer-axis slabs x{world}; per level: analysis halo fetch (1 band) and synthesis "
                                                               f"scatter-add (1 band) via RCCL send/recv, overlapped with the interior planes",
                       "path": "per-axis" if a.generic else ("fused3d" if d == 3 else "t-axis march + fused3d"),
-                      "coefficient_layout": "packed (reference)" if a.band_pitch == "packed" or sharded else "pitched bands (ndwt_band_pitch)"},
+                      "coefficient_layout": ("pitched local slabs owned by the sharded driver" if sharded else
+                                             "packed (reference)" if a.band_pitch == "packed" else "pitched bands (ndwt_band_pitch)")},
            "roofline": roofline, "roundtrip_rel_l2": rt_err}
     if pitched is not None:
         out["pitched_coefficients"] = pitched

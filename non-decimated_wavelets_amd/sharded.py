@@ -117,6 +117,39 @@ class HipSlabEngine:
         return buf[0, :sa], buf[1, m - sb:]
 
 
+_SKEW_BYTES = 256
+
+
+def _skewed_empty(shape, like):
+    """uninitialised tensor whose first element sits 256 bytes past its allocation's (power-of-two) alignment: the approximation
+    planes then differ from the packed detail bands of a level in their address bits below 1 KiB"""
+    n = 1
+    for v in shape:
+        n *= int(v)
+    skew = _SKEW_BYTES // like.element_size()
+    flat = torch.empty(n + skew, dtype=like.dtype, device=like.device)
+    return flat[skew:].view(tuple(shape))
+
+
+def _pitched_bands(nbands, band_shape, like):
+    """(nbands, *band_shape) tensor whose bands are each contiguous and `prod(band_shape)` + 256 bytes apart (a view of one
+    allocation): the 2^d band streams of a level no longer share their address bits below 1 KiB.  .contiguous() packs it."""
+    vol = 1
+    for v in band_shape:
+        vol *= int(v)
+    pitch = vol + _SKEW_BYTES // like.element_size()
+    flat = torch.empty(nbands * pitch, dtype=like.dtype, device=like.device)
+    strides = [1] * len(band_shape)
+    for i in range(len(band_shape) - 2, -1, -1):
+        strides[i] = strides[i + 1] * int(band_shape[i + 1])
+    return flat.as_strided((nbands,) + tuple(band_shape), (pitch,) + tuple(strides))
+
+
+def _bands_in_place(y):
+    """True when every band of y is contiguous (packed or pitched): the engines take band pointers"""
+    return y.dim() >= 2 and y[0].is_contiguous() and (y.shape[0] == 1 or y.stride(0) >= y[0].numel())
+
+
 class ShardedNdDwt:
     def __init__(self, wname, sizes, pres_l2_norm=False, precision="double", dilation="reference", group=None, device=None,
                  engine=None, synthesis_scheme="auto", overlap=True):
@@ -166,7 +199,7 @@ class ShardedNdDwt:
         shape = tuple(int(v) for v in shape)
         t = self._bufs.get(name)
         if t is None or tuple(t.shape) != shape or t.dtype != like.dtype or t.device != like.device:
-            t = torch.empty(shape, dtype=like.dtype, device=like.device)
+            t = _skewed_empty(shape, like)
             self._bufs[name] = t
         return t
 
@@ -295,7 +328,8 @@ class ShardedNdDwt:
         with the split-halo entry point read x and the two received halo buffers from where they are)."""
         nb, nbt = self.nb, self.nb + (self.nb - 1) * (level - 1)
         x_local = x_local.to(self.dtype).contiguous()
-        y = x_local.new_empty((nbt,) + tuple(x_local.shape))
+        # the local coefficient slab is this driver's own array: bands pitched (a strided view; .contiguous() packs it)
+        y = _pitched_bands(nbt, tuple(x_local.shape), x_local) if x_local.is_cuda else x_local.new_empty((nbt,) + tuple(x_local.shape))
         n, inner = self.n_local, tuple(x_local.shape[1:])
         split = bool(hasattr(self.engine, "analysis_split") and getattr(self.engine, "supports_split",
                                                                      getattr(self.engine, "supports_scatter", False)))
@@ -350,7 +384,9 @@ class ShardedNdDwt:
         """(bands, n_local, ..., n1) -> (n_local, ..., n1)"""
         nb = self.nb
         level = 1 + (y.shape[0] - nb) // (nb - 1)
-        y = y.to(self.dtype).contiguous()
+        y = y.to(self.dtype)
+        if not _bands_in_place(y):
+            y = y.contiguous()
         prev = y[0]
         for ind in range(1, level + 1):
             lev = level - ind + 1
