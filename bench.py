@@ -264,6 +264,7 @@ def main():
     pitched = None
     if not sharded and a.band_pitch == "packed" and not a.packed_only:
         lay["y"] = y = None
+        torch.cuda.empty_cache()                                  # (cfg5: 92 GiB; the pitched buffer is a little larger than the cached block)
         lay["pitch"] = plan.band_pitch()
         lay["y"] = torch.empty(nbands * lay["pitch"], device=dev, dtype=torch.float32)
         for _ in range(2):
