@@ -373,7 +373,7 @@ void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int
     *TX = 64;
     if (!inverse) {
         *TY = f64 ? (Lp >= 10 ? 16 : 8) : 16;                                     // double, db5/db6: 512 threads
-        if (!f64 && variant == 2 && (Lp == 8 || Lp == 12)) *TY = 32;            // float, tall tile (A/B)
+        if (!f64 && ew == 1 && ((variant == 2 && Lp == 8) || (variant != 1 && Lp >= 10 && Lp <= 16))) *TY = 32;   // float, tall tile: 10 .. 16 taps (8: A/B)
     } else if (f64) {
         *TY = (variant == 3 && Lp == 8) ? 8 : 16;                                 // lane-shift kernel 64x16; variant 3 = LDS kernel
     } else {
@@ -442,7 +442,7 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     // analysis: 512 workgroups 0.88 ms, 1024: 1.09 ms, 2048: 0.99 ms; 256^3 double synthesis: 256 workgroups 0.36 ms,
     // 640: 0.48 ms).  Workgroups per CU: synthesis 1 (1024 threads / 94 KB of LDS), analysis 2 (3 fit, 2 run faster).
     const bool small_inv = inverse && sizeof(T) == 4 && ew == 1 && variant == 3 && Lp == 8;   // 256-thread A/B variant
-    const int per_cu = inverse ? (small_inv ? 3 : 1) : (dil == 4 ? 1 : 2);
+    const int per_cu = inverse ? (small_inv ? 3 : 1) : ((dil == 4 || (sizeof(T) == 4 && TY == 32)) ? 1 : 2);   // 1024-thread tiles: one per CU
     const int target = p->target_blocks > 0 ? p->target_blocks : p->num_cus * per_cu;
     // analysis (2-3 workgroups per CU): more tiles than resident slots -> about 8 workgroups per CU; synthesis (1 per CU,
     // rounds are exact multiples of the CU count more often): one chunk per tile
@@ -463,7 +463,7 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
         if (use_y) rc = ew == 2 ? launch_inv3yc_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s) : launch_inv3y_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s);
     }
     if constexpr (sizeof(T) == 4) {
-        if (rc == -1 && Lp > 12 && ew == 1) rc = launch_long3_f32(inverse, a, t, vec4, td, s);
+        if (rc == -1 && Lp > 12 && ew == 1) rc = launch_long3_f32(inverse, a, t, vec4, variant, td, s);
     }
     if (rc == -1) rc = launch3<T>(inverse, a, t, vec4, ew != 1 ? 0 : variant, ew, td, s);
     prof_end(p, s, rc);

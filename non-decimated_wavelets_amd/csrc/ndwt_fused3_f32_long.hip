@@ -3,8 +3,15 @@
 // pair-packed kernel for mixed wavelets with odd tap padding).
 #include "ndwt_fused_kernels.h"
 namespace ndwt {
-int launch_long3_f32(bool inverse, const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, const void* taps_dev, hipStream_t s) {
+int launch_long3_f32(bool inverse, const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, int variant, const void* taps_dev, hipStream_t s) {
     if (!inverse) {
+        if (variant != 1) {       // default: tall 64x32 tile, 1024 threads (db7 analysis 1.45 -> 1.15 ms per launch; 16 taps spill 8 registers, -5 %)
+            switch (t.Lp) {
+                NDWT_FUSED_CASE(Fwd3, false, float, 14, 2)
+                NDWT_FUSED_CASE(Fwd3, false, float, 16, 2)
+                default: break;
+            }
+        }
         switch (t.Lp) {
             NDWT_FUSED_CASE(Fwd3, false, float, 14, 1)
             NDWT_FUSED_CASE(Fwd3, false, float, 16, 1)

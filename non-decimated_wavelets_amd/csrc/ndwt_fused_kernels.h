@@ -163,8 +163,8 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
         default: return -1;                                               \
     }
 
-// float analysis: 256-thread kernel for tap lengths <= 8, 512 threads (one column per thread) for 10 and 12;
-// variant 2 = tall 64x32 tile with 1024 threads (A/B runs)
+// float analysis: 256-thread kernel for tap lengths <= 8, the tall 64x32 tile with 1024 threads for 10 and 12 (and 14, 16:
+// ndwt_fused3_f32_long.hip); variant 1 = 512 threads, one column per thread (A/B; the kernel of interleaved complex data with 10 / 12 taps)
 #define NDWT_FUSED_SWITCH_FWD_F32(T)                                      \
     if (ew == 4) {                                                        \
         switch (t.Lp) {                                                   \
@@ -186,14 +186,15 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
             default: return -1;                                           \
         }                                                                 \
     }                                                                     \
-    if (variant == 2) { switch (t.Lp) { NDWT_FUSED_CASE(Fwd3, false, T, 8, 2) NDWT_FUSED_CASE(Fwd3, false, T, 12, 2) } }  \
+    if (variant == 2) { switch (t.Lp) { NDWT_FUSED_CASE(Fwd3, false, T, 8, 2) NDWT_FUSED_CASE(Fwd3, false, T, 10, 2) NDWT_FUSED_CASE(Fwd3, false, T, 12, 2) } }  \
+    if (variant == 1) { switch (t.Lp) { NDWT_FUSED_CASE(Fwd3, false, T, 10, 1) NDWT_FUSED_CASE(Fwd3, false, T, 12, 1) } }  \
     switch (t.Lp) {                                                       \
         NDWT_FUSED_CASE(Fwd3, false, T, 2, 0)                             \
         NDWT_FUSED_CASE(Fwd3, false, T, 4, 0)                             \
         NDWT_FUSED_CASE(Fwd3, false, T, 6, 0)                             \
         NDWT_FUSED_CASE(Fwd3, false, T, 8, 0)                             \
-        NDWT_FUSED_CASE(Fwd3, false, T, 10, 1)                            \
-        NDWT_FUSED_CASE(Fwd3, false, T, 12, 1)                            \
+        NDWT_FUSED_CASE(Fwd3, false, T, 10, 2)   /* 10 .. 16 taps: the tall tile (db6 analysis 1.33 -> 1.02 ms per launch) */ \
+        NDWT_FUSED_CASE(Fwd3, false, T, 12, 2)                            \
         default: return -1;                                               \
     }
 
