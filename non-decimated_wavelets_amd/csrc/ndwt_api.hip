@@ -373,7 +373,7 @@ void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int
     *TX = 64;
     if (!inverse) {
         *TY = f64 ? (Lp >= 10 ? 16 : 8) : 16;                                     // double, db5/db6: 512 threads
-        if (!f64 && ew == 1 && ((variant == 2 && Lp == 8) || (variant != 1 && Lp >= 10 && Lp <= 16))) *TY = 32;   // float, tall tile: 10 .. 16 taps (8: A/B)
+        if (!f64 && ew == 1 && ((variant == 2 && Lp <= 8) || (variant != 1 && Lp >= 10 && Lp <= 16))) *TY = 32;   // float, tall tile: 10 .. 16 taps (<= 8: A/B)
     } else if (f64) {
         *TY = (variant == 3 && Lp == 8) ? 8 : 16;                                 // lane-shift kernel 64x16; variant 3 = LDS kernel
     } else {
@@ -429,8 +429,13 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     }
 #endif
     int TX = 0, TY = 0;
-    const int variant = inverse ? p->variant_inv : p->variant_fwd;
+    int variant = inverse ? p->variant_inv : p->variant_fwd;
     const int ew = dil > 1 ? dil : (int)p->comp;
+    // float analysis, 6 and 8 taps: the tall 64x32 tile with 1024 threads (variant 2) where the volume has the tiles to fill the chip
+    // with it (512^3 db4: 0.95 -> 0.85 ms per launch, db3 -4 %; db1 / db2 +3 %, 256^3 even); NDWT_VARIANT_FWD=3 keeps the 64x16 tile
+    if (!inverse && sizeof(T) == 4 && ew == 1 && variant == 0 && Lp >= 6 && Lp <= 8 &&
+        (long long)((a.n1 + 63) / 64) * ((a.n2 + 31) / 32) * a.nbatch >= 32)
+        variant = 2;
     fused3_tile_shape(sizeof(T) == 8, inverse, ew != 1 ? 0 : variant, Lp, &TX, &TY, ew);
     bool use_y = false;                                   // float synthesis default: the pair-packed kernel and its tile
     if constexpr (sizeof(T) == 4) {

@@ -186,7 +186,7 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
             default: return -1;                                           \
         }                                                                 \
     }                                                                     \
-    if (variant == 2) { switch (t.Lp) { NDWT_FUSED_CASE(Fwd3, false, T, 8, 2) NDWT_FUSED_CASE(Fwd3, false, T, 10, 2) NDWT_FUSED_CASE(Fwd3, false, T, 12, 2) } }  \
+    if (variant == 2) { switch (t.Lp) { NDWT_FUSED_CASE(Fwd3, false, T, 2, 2) NDWT_FUSED_CASE(Fwd3, false, T, 4, 2) NDWT_FUSED_CASE(Fwd3, false, T, 6, 2) NDWT_FUSED_CASE(Fwd3, false, T, 8, 2) } }  \
     if (variant == 1) { switch (t.Lp) { NDWT_FUSED_CASE(Fwd3, false, T, 10, 1) NDWT_FUSED_CASE(Fwd3, false, T, 12, 1) } }  \
     switch (t.Lp) {                                                       \
         NDWT_FUSED_CASE(Fwd3, false, T, 2, 0)                             \
