@@ -102,9 +102,9 @@ template <bool NT_LD, bool NT_ST> __global__ void __launch_bounds__(512) fan_in_
     if (threadIdx.x == 100000) unused_lds[0] = 0.f;
 }
 
-template <bool NT_LD, bool NT_ST> __global__ void __launch_bounds__(256) fan_out_tiled(const float* in, Bands out, int zchunk) {
+template <bool NT_LD, bool NT_ST, int TY = 16> __global__ void __launch_bounds__(TY * 16) fan_out_tiled(const float* in, Bands out, int zchunk) {
     int zbeg;
-    const long long off = tile_base<16, 256>(zbeg, zchunk);
+    const long long off = tile_base<TY, TY * 16>(zbeg, zchunk);
     v4 cur = ld<NT_LD>(in + off + (long long)zbeg * N * N), nxt = cur;
     for (int z = zbeg; z < zbeg + zchunk; ++z) {
         if (z + 1 < zbeg + zchunk) nxt = ld<NT_LD>(in + off + (long long)(z + 1) * N * N);
@@ -112,6 +112,13 @@ template <bool NT_LD, bool NT_ST> __global__ void __launch_bounds__(256) fan_out
         for (int b = 0; b < 8; ++b) st<NT_ST>(out.p[b] + off + (long long)z * N * N, cur * (float)(b + 1));
         cur = nxt;
     }
+}
+
+// planes per workgroup so that `blocks` workgroups of 64 x TY tiles cover the volume exactly (anything else would run off the arrays)
+static int checked_zchunk(int blocks, int ty) {
+    const int tiles = (N / 64) * (N / ty);
+    if (blocks % tiles != 0 || N % (blocks / tiles) != 0) { printf("bad launch geometry\n"); exit(1); }
+    return N / (blocks / tiles);
 }
 
 template <class F> static float time_ms(F&& launch) {
@@ -157,19 +164,23 @@ int main() {
         float t;
         t = time_ms([&] { hipLaunchKernelGGL(fan_in_linear, dim3(256 * 8), dim3(256), 0, 0, b, vol); });
         printf("fan-in  8->1 linear  %s %.3f ms  %.0f GB/s\n", lay, t, gb / t * 1e3);
-        t = time_ms([&] { hipLaunchKernelGGL((fan_in_tiled<false, false>), dim3(256), dim3(512), 96 * 1024, 0, b, vol, 256); });
+        t = time_ms([&] { hipLaunchKernelGGL((fan_in_tiled<false, false>), dim3(256), dim3(512), 96 * 1024, 0, b, vol, checked_zchunk(256, 32)); });
         printf("fan-in  8->1 tiled   %s %.3f ms  %.0f GB/s\n", lay, t, gb / t * 1e3);
-        t = time_ms([&] { hipLaunchKernelGGL((fan_in_tiled<true, false>), dim3(256), dim3(512), 96 * 1024, 0, b, vol, 256); });
+        t = time_ms([&] { hipLaunchKernelGGL((fan_in_tiled<true, false>), dim3(256), dim3(512), 96 * 1024, 0, b, vol, checked_zchunk(256, 32)); });
         printf("fan-in  8->1 tiled   %s %.3f ms  %.0f GB/s  (nontemporal loads)\n", lay, t, gb / t * 1e3);
-        t = time_ms([&] { hipLaunchKernelGGL((fan_in_tiled<true, true>), dim3(256), dim3(512), 96 * 1024, 0, b, vol, 256); });
+        t = time_ms([&] { hipLaunchKernelGGL((fan_in_tiled<true, true>), dim3(256), dim3(512), 96 * 1024, 0, b, vol, checked_zchunk(256, 32)); });
         printf("fan-in  8->1 tiled   %s %.3f ms  %.0f GB/s  (nontemporal loads and stores)\n", lay, t, gb / t * 1e3);
         t = time_ms([&] { hipLaunchKernelGGL(fan_out_linear, dim3(256 * 8), dim3(256), 0, 0, vol, b); });
         printf("fan-out 1->8 linear  %s %.3f ms  %.0f GB/s\n", lay, t, gb / t * 1e3);
-        t = time_ms([&] { hipLaunchKernelGGL((fan_out_tiled<false, false>), dim3(512), dim3(256), 0, 0, vol, b, 256); });
+        t = time_ms([&] { hipLaunchKernelGGL((fan_out_tiled<false, false>), dim3(512), dim3(256), 0, 0, vol, b, checked_zchunk(512, 16)); });
         printf("fan-out 1->8 tiled   %s %.3f ms  %.0f GB/s  (512 workgroups)\n", lay, t, gb / t * 1e3);
-        t = time_ms([&] { hipLaunchKernelGGL((fan_out_tiled<false, true>), dim3(512), dim3(256), 0, 0, vol, b, 256); });
+        t = time_ms([&] { hipLaunchKernelGGL((fan_out_tiled<false, true>), dim3(512), dim3(256), 0, 0, vol, b, checked_zchunk(512, 16)); });
         printf("fan-out 1->8 tiled   %s %.3f ms  %.0f GB/s  (512 workgroups, nontemporal stores)\n", lay, t, gb / t * 1e3);
-        t = time_ms([&] { hipLaunchKernelGGL((fan_out_tiled<false, false>), dim3(2048), dim3(256), 0, 0, vol, b, 64); });
+        t = time_ms([&] { hipLaunchKernelGGL((fan_out_tiled<false, true, 32>), dim3(256), dim3(512), 0, 0, vol, b, checked_zchunk(256, 32)); });
+        printf("fan-out 1->8 tiled   %s %.3f ms  %.0f GB/s  (64x32 tiles, 256 workgroups of 512 threads, nontemporal stores)\n", lay, t, gb / t * 1e3);
+        t = time_ms([&] { hipLaunchKernelGGL((fan_out_tiled<false, true, 64>), dim3(256), dim3(1024), 0, 0, vol, b, checked_zchunk(256, 64)); });
+        printf("fan-out 1->8 tiled   %s %.3f ms  %.0f GB/s  (64x64 tiles, 256 workgroups of 1024 threads, nontemporal stores)\n", lay, t, gb / t * 1e3);
+        t = time_ms([&] { hipLaunchKernelGGL((fan_out_tiled<false, false>), dim3(2048), dim3(256), 0, 0, vol, b, checked_zchunk(2048, 16)); });
         printf("fan-out 1->8 tiled   %s %.3f ms  %.0f GB/s  (2048 workgroups)\n", lay, t, gb / t * 1e3);
     }
     return 0;
