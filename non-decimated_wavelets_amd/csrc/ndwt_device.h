@@ -69,11 +69,18 @@ template <int I, int N, class F> NDWT_DEV void static_for(F&& f) {
 #define NDWT_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 #endif
 
-// store of data this kernel writes once and never reads back: nontemporal, so that the output streams do not displace the input
-// lines neighbouring tiles are about to share in L2 (tools/micro/stream_pattern: 8 -> 1 copy 0.92 -> 0.86 ms, 1 -> 8 0.98 -> 0.96)
+// store of data this kernel writes once and never reads back: nontemporal for float data, so that the output streams do not
+// displace the input lines neighbouring tiles are about to share in L2 (tools/micro/stream_pattern: 8 -> 1 copy 0.92 -> 0.86 ms,
+// 1 -> 8 0.98 -> 0.96; cfg3 step -2 %, 2-D -5 %).  Double keeps plain stores: at 512^3 the nontemporal form takes the analysis
+// kernel (32-byte stores per lane) from 2.11 to 2.81 ms per launch and the synthesis kernel from 2.26 to 2.32 ms.
 template <class V> NDWT_DEV void stream_store(V* p, V v) {
 #if !defined(NDWT_HOST_EMU) && !defined(NDWT_NO_NT_STORE)
+#ifdef NDWT_NT_ALL
     __builtin_nontemporal_store(v, p);
+    return;
+#endif
+    if constexpr (sizeof(v[0]) == 4) __builtin_nontemporal_store(v, p);
+    else *p = v;
 #else
     *p = v;
 #endif

@@ -12,6 +12,13 @@ int launch_fwd3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4,
             default: return -1;
         }
     }
+    if (variant == 1) {       // 64x16 tile, 512 threads, one column per thread (A/B)
+        switch (t.Lp) {
+            NDWT_FUSED_CASE(Fwd3, false, double, 6, 1)
+            NDWT_FUSED_CASE(Fwd3, false, double, 8, 1)
+            default: break;
+        }
+    }
     switch (t.Lp) {
         NDWT_FUSED_CASE(Fwd3, false, double, 2, 0)
         NDWT_FUSED_CASE(Fwd3, false, double, 4, 0)

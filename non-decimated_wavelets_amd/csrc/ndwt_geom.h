@@ -10,9 +10,9 @@ namespace ndwt {
 // planes each; the chunk is sized so the grid has at most ~target_blocks workgroups (the number that is
 // resident on the chip at once: one full round, no partial second round) while the (L-1)-plane march
 // prologue stays a small fraction of the chunk.
-// many_blocks > 0: when one chunk per tile already gives more workgroups than fit at once, cut the chunks further until
-// there are about many_blocks of them (several rounds of small workgroups balance better than 1.3 rounds of big ones:
-// 4-D analysis, 1024 tiles, 768 resident: 2.19 ms with 1024 workgroups, 1.88 ms with 2048).
+// With more tiles than resident slots the chunk count is the one with the fewest plane steps over all rounds (a partial last
+// round costs a whole one: 4-D analysis, 1024 tiles, 768 resident: 2.19 ms with 1024 workgroups, 1.88 ms with 2048; 768^3
+// synthesis, 288 tiles on 256 CUs: 5.6 ms in one chunk, 8 chunks = 9 full rounds).  many_blocks is no longer used.
 template <typename T>
 inline void fused3_geometry(Fused3Args<T>& a, int TX, int TY, int Lp, int target_blocks = 2048, int force_zchunk = 0,
                             int many_blocks = 0) {
@@ -22,11 +22,23 @@ inline void fused3_geometry(Fused3Args<T>& a, int TX, int TY, int Lp, int target
     a.rs = a.n1;
     long long per_chunk = (long long)a.ntx * a.nty * a.nbatch;
     int want = (int)(target_blocks / per_chunk);
-    if (want < 1) want = many_blocks > 0 ? (int)((many_blocks + per_chunk - 1) / per_chunk) : 1;
-    if (want < 1) want = 1;
-    int zc = (a.n3 + want - 1) / want;
     int min_chunk = 4 * (Lp - 1);                 // prologue <= 25 % of the chunk
     if (min_chunk < 8) min_chunk = 8;
+    if (want < 1) {
+        // more tiles than resident slots: the launch runs in rounds of `target_blocks` workgroups and a partial last round costs
+        // a whole one (768^3 synthesis: 288 tiles on 256 CUs = 2 rounds of 775 planes, 5.6 ms; cut into 8 chunks = 9 full rounds
+        // of 103 planes, 3.6 ms).  Pick the chunk count with the fewest plane steps, a little in favour of fewer rounds.
+        (void)many_blocks;
+        double best = 0.0;
+        want = 1;
+        const int max_chunks = a.n3 / min_chunk > 0 ? a.n3 / min_chunk : 1;
+        for (int c = 1; c <= max_chunks && c <= 64; ++c) {
+            const long long rounds = (per_chunk * c + target_blocks - 1) / target_blocks;
+            const double cost = (double)rounds * ((a.n3 + c - 1) / c + Lp - 1) * (1.0 + 0.01 * (double)(rounds - 1));
+            if (c == 1 || cost < best) { best = cost; want = c; }
+        }
+    }
+    int zc = (a.n3 + want - 1) / want;
     // small problems leave most CUs idle at that chunk size and every workgroup is a serial march of ~2 us plane steps:
     // fill the chip instead (one round of workgroups, chunks down to 2 planes; the prologue re-reads come from L2 at
     // these sizes).  64^3 db4 L3: 433 -> 129 us per dec+rec, 128^3: 503 -> 181 us.
