@@ -9,5 +9,5 @@ for o in "$(dirname "$0")"/../non-decimated_wavelets_amd/csrc/build/*.o; do
   $B/llvm-objcopy --dump-section .hip_fatbin=$T/$b.fat "$o" 2>/dev/null || continue
   $B/clang-offload-bundler --unbundle --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --input=$T/$b.fat --output=$T/$b.elf 2>/dev/null || continue
   $B/llvm-readelf --notes $T/$b.elf 2>/dev/null | grep -E "^\s+\.(name|vgpr_count|vgpr_spill_count):" | paste - - - | sed -E 's/\s+/ /g'
-done | { if [ "$1" = all ]; then cat; else awk '$NF + 0 > 0'; fi; } | sed -E 's/ \.name: _ZN4ndwt[0-9]+fused[23]_kernelINS_[0-9]/ /; s/EEEEEvNT_.*(\.vgpr_count)/ \1/' | $B/llvm-cxxfilt 2>/dev/null
+done | awk -v all="$1" 'all == "all" || $NF + 0 > 0' | sed -E 's/ \.name: _ZN4ndwt[0-9]+fused[23]_kernelINS_[0-9]/ /; s/EEEEEvNT_.*(\.vgpr_count)/ \1/'
 rm -rf $T
