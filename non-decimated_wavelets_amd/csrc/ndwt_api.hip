@@ -392,6 +392,17 @@ static bool inv3y_plan_ok(const ndwt_plan* p, int Lp) {
     return p->dims[0] * p->comp * p->dims[1] < (1LL << 30);
 }
 
+// Nontemporal output stores: float data whose output rows are whole 128-byte lines (a nontemporal store of a partly covered line
+// is a read-modify-write in memory; plain stores of neighbouring tiles merge in L2).  Double never (ndwt_device.h: stream_store).
+template <typename T> static int nt_store_ok(long long rs, long long plane, long long bstride, T* const* out, int nout) {
+    if (sizeof(T) != 4) return 0;
+    const long long line = 128 / (long long)sizeof(T);
+    if (rs % line != 0 || plane % line != 0 || bstride % line != 0) return 0;
+    for (int b = 0; b < nout; ++b)
+        if (((uintptr_t)out[b]) % 128 != 0) return 0;
+    return 1;
+}
+
 // one fused 3-D launch over `nbatch` volumes. n3 = output planes; z_wrap=false: inputs carry the z halo
 template <typename T>
 static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* in, T* const* out, long long n3, long long nbatch,
@@ -459,6 +470,7 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
         a.in_bstride = a.out_bstride = p->dims[0];                         // sub-lattice offset along y ...
         a.in_bstride2 = a.out_bstride2 = p->dims[0] * p->dims[1];          // ... and along z
     }
+    a.nt = nt_store_ok<T>(a.rs, a.plane, out_bstride, out, nout);
     FusedTapsD t = fused_taps(p, Lp, inverse);
     const void* td = p->taps_dev[inverse ? 1 : 0];
     if (!td) return fail(NDWT_ERR_UNSUPPORTED, "plan has no device tap table");
@@ -516,6 +528,7 @@ static int fused2_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     const int ew2 = dil > 1 ? dil : (int)p->comp;
     fused2_geometry(a, fused2_tile_width(inverse, Lp, ew2), Lp, p->target_blocks > 0 ? p->target_blocks * 2 : 2048, p->force_zchunk);
     if (dil > 1) a.rs = (int)(dil * p->dims[0]);   // 8 waves per CU: one round (measured optimum 1024^2 .. 4096^2)
+    a.nt = nt_store_ok<T>(a.rs, a.rs, out_bstride, out, nout);
     const void* td = p->taps_dev[inverse ? 1 : 0];
     if (!td) return fail(NDWT_ERR_UNSUPPORTED, "plan has no device tap table");
     prof_begin(p, inverse ? NDWT_KERNEL_FUSED_SYNTHESIS : NDWT_KERNEL_FUSED_ANALYSIS, s);

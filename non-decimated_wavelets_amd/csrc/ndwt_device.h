@@ -73,17 +73,16 @@ template <int I, int N, class F> NDWT_DEV void static_for(F&& f) {
 // displace the input lines neighbouring tiles are about to share in L2 (tools/micro/stream_pattern: 8 -> 1 copy 0.92 -> 0.86 ms,
 // 1 -> 8 0.98 -> 0.96; cfg3 step -2 %, 2-D -5 %).  Double keeps plain stores: at 512^3 the nontemporal form takes the analysis
 // kernel (32-byte stores per lane) from 2.11 to 2.81 ms per launch and the synthesis kernel from 2.26 to 2.32 ms.
-template <class V> NDWT_DEV void stream_store(V* p, V v) {
+// nt: set by the host for float data whose rows are whole 128-byte lines (300-float rows: a nontemporal store of a partly
+// covered line costs a read-modify-write in memory -- 300x400x500 analysis 0.89 ms against 0.51 ms with plain stores, which L2 merges)
+template <class V> NDWT_DEV void stream_store(V* p, V v, int nt) {
 #if !defined(NDWT_HOST_EMU) && !defined(NDWT_NO_NT_STORE)
-#ifdef NDWT_NT_ALL
-    __builtin_nontemporal_store(v, p);
-    return;
+    if constexpr (sizeof(v[0]) == 4) {
+        if (nt) { __builtin_nontemporal_store(v, p); return; }
+    }
 #endif
-    if constexpr (sizeof(v[0]) == 4) __builtin_nontemporal_store(v, p);
-    else *p = v;
-#else
+    (void)nt;
     *p = v;
-#endif
 }
 NDWT_DEV float ndwt_sqrt(float v) { return __builtin_sqrtf(v); }
 NDWT_DEV double ndwt_sqrt(double v) { return __builtin_sqrt(v); }
@@ -201,6 +200,7 @@ template <typename T> struct Fused3Args {
     // hard with shrink_hard) -- the thresholding of the detail bands fused into the reconstruction
     T shrink_thr;
     int shrink_mask, shrink_hard;
+    int nt;                // nontemporal output stores (float data whose rows are whole 128-byte lines)
     long long* stamps;     // diagnostic builds (-DNDWT_STAMPS) only: per wave, cycles spent in each phase of the plane loop
 };
 
@@ -494,10 +494,10 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
             T* b01 = a.out[2 * q + 4] + off;
             T* b11 = a.out[2 * q + 5] + off;
             if constexpr (VEC4) {
-                stream_store(reinterpret_cast<v4*>(b00), o00);
-                stream_store(reinterpret_cast<v4*>(b10), o10);
-                stream_store(reinterpret_cast<v4*>(b01), o01);
-                stream_store(reinterpret_cast<v4*>(b11), o11);
+                stream_store(reinterpret_cast<v4*>(b00), o00, a.nt);
+                stream_store(reinterpret_cast<v4*>(b10), o10, a.nt);
+                stream_store(reinterpret_cast<v4*>(b01), o01, a.nt);
+                stream_store(reinterpret_cast<v4*>(b11), o11, a.nt);
             } else {
                 NDWT_UNROLL
                 for (int e = 0; e < 4; ++e) {
@@ -702,7 +702,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
                         if (gy < a.n2) {
                             T* dst = a.out[0] + obase + (long long)z * a.plane + (long long)gy * a.rs + gx;
                             if constexpr (VEC4 && CH == 2) {
-                                if (gx < a.n1) stream_store(reinterpret_cast<v2*>(dst), v2{o[0], o[CH - 1]});
+                                if (gx < a.n1) stream_store(reinterpret_cast<v2*>(dst), v2{o[0], o[CH - 1]}, a.nt);
                             } else {
                                 NDWT_SFOR(sub, CH)
                                     if (gx + sub < a.n1) dst[sub] = o[sub];
@@ -1003,7 +1003,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
                         if (gy < a.n2) {
                             T* dst = a.out[0] + obase + (long long)z * a.plane + (long long)gy * a.rs + gx;
                             if constexpr (VEC4 && CH == 2) {
-                                if (gx < a.n1) stream_store(reinterpret_cast<v2*>(dst), v2{st.zacc[k][done][i * CH], st.zacc[k][done][i * CH + CH - 1]});
+                                if (gx < a.n1) stream_store(reinterpret_cast<v2*>(dst), v2{st.zacc[k][done][i * CH], st.zacc[k][done][i * CH + CH - 1]}, a.nt);
                             } else {
                                 NDWT_SFOR(sub, CH)
                                     if (gx + sub < a.n1) dst[sub] = st.zacc[k][done][i * CH + sub];
@@ -1190,16 +1190,15 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
     }
     // the output plane is written once and never read back by this kernel: a nontemporal store keeps it from displacing the
     // band lines that neighbouring tiles are about to share in L2 (tools/micro/stream_pattern: 8 -> 1 copy 0.92 -> 0.86 ms)
-    template <class V> static NDWT_DEV void gstore(void* base, unsigned off, V v) {
+    template <class V> static NDWT_DEV void gstore(void* base, unsigned off, V v, int nt) {
 #ifndef NDWT_NO_NT_STORE
-        __builtin_nontemporal_store(v, reinterpret_cast<__attribute__((address_space(1))) V*>((gptr)uniform_bits(base) + off));
-#else
-        *reinterpret_cast<__attribute__((address_space(1))) V*>((gptr)uniform_bits(base) + off) = v;
+        if (nt) { __builtin_nontemporal_store(v, reinterpret_cast<__attribute__((address_space(1))) V*>((gptr)uniform_bits(base) + off)); return; }
 #endif
+        *reinterpret_cast<__attribute__((address_space(1))) V*>((gptr)uniform_bits(base) + off) = v;
     }
 #else
     template <class V> static NDWT_DEV V gload(const void* base, unsigned off) { return *reinterpret_cast<const V*>((const char*)base + off); }
-    template <class V> static NDWT_DEV void gstore(void* base, unsigned off, V v) { *reinterpret_cast<V*>((char*)base + off) = v; }
+    template <class V> static NDWT_DEV void gstore(void* base, unsigned off, V v, int) { *reinterpret_cast<V*>((char*)base + off) = v; }
 #endif
 
     // ---- packed FMAs with explicit operand selection (v_pk_fma_f32 op_sel / neg modifiers) ----
@@ -1432,10 +1431,10 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
                     const v2 o = st.zacc[k][done];
                     T* dst = a.out[0] + obase + (long long)z * a.plane;   // wave-uniform
                     if constexpr (VEC4) {
-                        gstore<v2>(dst, st.ooff[k], o);
+                        gstore<v2>(dst, st.ooff[k], o, a.nt);
                     } else {
-                        gstore<T>(dst, st.ooff[k], o.x);
-                        if (st.ostore[k] == 2) gstore<T>(dst, st.ooff[k] + (unsigned)sizeof(T), o.y);
+                        gstore<T>(dst, st.ooff[k], o.x, 0);
+                        if (st.ostore[k] == 2) gstore<T>(dst, st.ooff[k] + (unsigned)sizeof(T), o.y, 0);
                     }
                 }
             }
@@ -1559,6 +1558,7 @@ template <typename T> struct Fused2Args {
     int rs;                // elements between rows (n1; a level dilated by s: s * n1, the s row sub-lattices are the batch items)
     T shrink_thr;          // synthesis: shrink input band b on load when bit b of shrink_mask is set
     int shrink_mask, shrink_hard;
+    int nt;                // nontemporal output stores (see Fused3Args)
 };
 
 struct Tile2Coord {
@@ -1667,10 +1667,10 @@ template <typename T, int L_, bool VEC4_, int WPE_ = 4, int EW_ = 1> struct Fwd2
         v4 o0 = {xlo[0].x, xlo[1].x, xlo[2].x, xlo[3].x}, o1 = {xhi[0].x, xhi[1].x, xhi[2].x, xhi[3].x};
         v4 o2 = {xlo[0].y, xlo[1].y, xlo[2].y, xlo[3].y}, o3 = {xhi[0].y, xhi[1].y, xhi[2].y, xhi[3].y};
         if constexpr (VEC4) {
-            stream_store(reinterpret_cast<v4*>(a.out[0] + off), o0);
-            stream_store(reinterpret_cast<v4*>(a.out[1] + off), o1);
-            stream_store(reinterpret_cast<v4*>(a.out[2] + off), o2);
-            stream_store(reinterpret_cast<v4*>(a.out[3] + off), o3);
+            stream_store(reinterpret_cast<v4*>(a.out[0] + off), o0, a.nt);
+            stream_store(reinterpret_cast<v4*>(a.out[1] + off), o1, a.nt);
+            stream_store(reinterpret_cast<v4*>(a.out[2] + off), o2, a.nt);
+            stream_store(reinterpret_cast<v4*>(a.out[3] + off), o3, a.nt);
         } else {
             NDWT_SFOR(e, 4)
                 if (gx + e < a.n1) { a.out[0][off + e] = o0[e]; a.out[1][off + e] = o1[e]; a.out[2][off + e] = o2[e]; a.out[3][off + e] = o3[e]; }
@@ -1781,7 +1781,7 @@ template <typename T, int L_, bool VEC4_, int WPE_ = 4, int EW_ = 1> struct Inv2
         if (tid < GL || tid >= 64 - GR || gx >= a.n1) return;
         long long off = obase + (long long)y * a.rs + gx;
         if constexpr (VEC4) {
-            stream_store(reinterpret_cast<v4*>(a.out[0] + off), v4{st.yacc[done][0], st.yacc[done][1], st.yacc[done][2], st.yacc[done][3]});
+            stream_store(reinterpret_cast<v4*>(a.out[0] + off), v4{st.yacc[done][0], st.yacc[done][1], st.yacc[done][2], st.yacc[done][3]}, a.nt);
         } else {
             NDWT_SFOR(e, 4)
                 if (gx + e < a.n1) a.out[0][off + e] = st.yacc[done][e];
