@@ -13,6 +13,13 @@
 #include "ndwt_geom.h"
 #include "ndwt_fused_tile.h"
 
+// The pair-packed synthesis instantiations (10 tap lengths x 2 access widths x 2 depths x tiles) live in translation units of their
+// own (EMU_PART 9 .. 12): as part of emu3<float, true> they made that one unit compile for 6.5 minutes.
+int emu_y_small(int depth, int Lp, int vec4, ndwt::Fused3Args<float>& a, const double* lo, const double* hi);
+int emu_y_small2(int Lp, int vec4, ndwt::Fused3Args<float>& a, const double* lo, const double* hi);
+int emu_y_prod(int depth, int Lp, int vec4, ndwt::Fused3Args<float>& a, const double* lo, const double* hi);
+int emu_yc_small(int depth, int Lp, int vec4, ndwt::Fused3Args<float>& a, const double* lo, const double* hi);
+
 namespace {
 
 template <class State, int NT> struct EmuExec {
@@ -175,8 +182,7 @@ int emu3(int Lp, int vec4, const T* in, T* out, int n1, int n2, int n3, int nbat
         if constexpr (INV && sizeof(T) == 4) {   // pair-packed synthesis on (re, im) pairs: small tile, every tap length up to 12
             if ((variant == 5 || variant == 8) && small_tile && Lp <= 12) {
                 geometry(16, 8);
-                return variant == 5 ? dispatchY<T, 16, 8, 128, true, 1, 2>(Lp, vec4, a, lo, hi)
-                                    : dispatchY<T, 16, 8, 512, true, 2, 2>(Lp, vec4, a, lo, hi);
+                return emu_yc_small(variant == 5 ? 1 : 2, Lp, vec4, a, lo, hi);
             }
         }
         if (small_tile) {
@@ -196,12 +202,10 @@ int emu3(int Lp, int vec4, const T* in, T* out, int n1, int n2, int n3, int nbat
         if (variant == 5 || variant == 8) {
             if (small_tile) {
                 geometry(16, 8);
-                return variant == 5 ? dispatchY<T, 16, 8, 128, true, 1>(Lp, vec4, a, lo, hi)
-                                    : dispatchY<T, 16, 8, 512, true, 2>(Lp, vec4, a, lo, hi);   // 8 waves: both refill schedules run
+                return variant == 5 ? emu_y_small(1, Lp, vec4, a, lo, hi) : emu_y_small2(Lp, vec4, a, lo, hi);   // depth 2 on 8 waves: both refill schedules run
             }
             geometry(ndwt::kInv3YTX, ndwt::kInv3YTY);
-            return variant == 5 ? dispatchY<T, ndwt::kInv3YTX, ndwt::kInv3YTY, 1024, false, 1>(Lp, vec4, a, lo, hi)
-                                : dispatchY<T, ndwt::kInv3YTX, ndwt::kInv3YTY, 1024, false, 2>(Lp, vec4, a, lo, hi);
+            return emu_y_prod(variant == 5 ? 1 : 2, Lp, vec4, a, lo, hi);
         }
     }
     if (small_tile) {   // a second tile shape exercises different item/lane mappings
@@ -390,6 +394,29 @@ int emu_axisx(int syn, int L, int ew, int vec4, const T* in0, const T* in1, T* o
 #define EMU_ALL 0
 #endif
 #define EMU_IN(part) (EMU_ALL || EMU_PART == part)
+
+#if EMU_IN(9)
+int emu_y_small(int depth, int Lp, int vec4, ndwt::Fused3Args<float>& a, const double* lo, const double* hi) {
+    return depth == 1 ? dispatchY<float, 16, 8, 128, true, 1>(Lp, vec4, a, lo, hi) : -2;
+}
+#endif
+#if EMU_IN(10)
+int emu_y_small2(int Lp, int vec4, ndwt::Fused3Args<float>& a, const double* lo, const double* hi) {
+    return dispatchY<float, 16, 8, 512, true, 2>(Lp, vec4, a, lo, hi);
+}
+#endif
+#if EMU_IN(11)
+int emu_y_prod(int depth, int Lp, int vec4, ndwt::Fused3Args<float>& a, const double* lo, const double* hi) {
+    return depth == 1 ? dispatchY<float, ndwt::kInv3YTX, ndwt::kInv3YTY, 1024, false, 1>(Lp, vec4, a, lo, hi)
+                      : dispatchY<float, ndwt::kInv3YTX, ndwt::kInv3YTY, 1024, false, 2>(Lp, vec4, a, lo, hi);
+}
+#endif
+#if EMU_IN(12)
+int emu_yc_small(int depth, int Lp, int vec4, ndwt::Fused3Args<float>& a, const double* lo, const double* hi) {
+    return depth == 1 ? dispatchY<float, 16, 8, 128, true, 1, 2>(Lp, vec4, a, lo, hi)
+                      : dispatchY<float, 16, 8, 512, true, 2, 2>(Lp, vec4, a, lo, hi);
+}
+#endif
 
 extern "C" {
 #if EMU_IN(1)
