@@ -460,9 +460,8 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     const bool small_inv = inverse && sizeof(T) == 4 && ew == 1 && variant == 3 && Lp == 8;   // 256-thread A/B variant
     const int per_cu = inverse ? (small_inv ? 3 : 1) : ((dil == 4 || (sizeof(T) == 4 && TY == 32)) ? 1 : 2);   // 1024-thread tiles: one per CU
     const int target = p->target_blocks > 0 ? p->target_blocks : p->num_cus * per_cu;
-    // analysis (2-3 workgroups per CU): more tiles than resident slots -> about 8 workgroups per CU; synthesis (1 per CU,
-    // rounds are exact multiples of the CU count more often): one chunk per tile
-    fused3_geometry(a, TX, TY, Lp, target, zc_force, inverse || p->target_blocks > 0 ? 0 : p->num_cus * 8);
+    // more tiles than resident slots: fused3_geometry picks the chunk count with the fewest plane steps over all rounds
+    fused3_geometry(a, TX, TY, Lp, target, zc_force);
     if (dil > 1) {
         a.rs = (int)(dil * p->dims[0]);
         a.plane = (long long)dil * p->dims[0] * p->dims[1];

@@ -12,10 +12,9 @@ namespace ndwt {
 // prologue stays a small fraction of the chunk.
 // With more tiles than resident slots the chunk count is the one with the fewest plane steps over all rounds (a partial last
 // round costs a whole one: 4-D analysis, 1024 tiles, 768 resident: 2.19 ms with 1024 workgroups, 1.88 ms with 2048; 768^3
-// synthesis, 288 tiles on 256 CUs: 5.6 ms in one chunk, 8 chunks = 9 full rounds).  many_blocks is no longer used.
+// synthesis, 288 tiles on 256 CUs: 5.6 ms in one chunk, 8 chunks = 9 full rounds).
 template <typename T>
-inline void fused3_geometry(Fused3Args<T>& a, int TX, int TY, int Lp, int target_blocks = 2048, int force_zchunk = 0,
-                            int many_blocks = 0) {
+inline void fused3_geometry(Fused3Args<T>& a, int TX, int TY, int Lp, int target_blocks = 2048, int force_zchunk = 0) {
     a.ntx = (a.n1 + TX - 1) / TX;
     a.nty = (a.n2 + TY - 1) / TY;
     a.plane = (long long)a.n1 * a.n2;             // dense volume; a dilated launch overrides rs / plane afterwards
@@ -28,7 +27,6 @@ inline void fused3_geometry(Fused3Args<T>& a, int TX, int TY, int Lp, int target
         // more tiles than resident slots: the launch runs in rounds of `target_blocks` workgroups and a partial last round costs
         // a whole one (768^3 synthesis: 288 tiles on 256 CUs = 2 rounds of 775 planes, 5.6 ms; cut into 8 chunks = 9 full rounds
         // of 103 planes, 3.6 ms).  Pick the chunk count with the fewest plane steps, a little in favour of fewer rounds.
-        (void)many_blocks;
         double best = 0.0;
         want = 1;
         const int max_chunks = a.n3 / min_chunk > 0 ? a.n3 / min_chunk : 1;
