@@ -444,10 +444,14 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     const int ew = dil > 1 ? dil : (int)p->comp;
     // float analysis, 6 and 8 taps: the tall 64x32 tile with 1024 threads (variant 2) where the volume has the tiles to fill the chip
     // with it (512^3 db4: 0.95 -> 0.85 ms per launch, db3 -4 %; db1 / db2 +3 %, 256^3 even); NDWT_VARIANT_FWD=3 keeps the 64x16 tile
+    // ... and the same for interleaved complex64 (384^3 db4: 1.19 -> 1.03 ms per launch); NDWT_VARIANT_FWD=3 keeps the 64x16 tile
+    const bool cplx_tall = !inverse && sizeof(T) == 4 && ew == 2 && dil == 1 && variant == 0 && Lp >= 6 && Lp <= 8 &&
+                           (long long)((a.n1 + 63) / 64) * ((a.n2 + 31) / 32) * a.nbatch >= 32;
     if (!inverse && sizeof(T) == 4 && ew == 1 && variant == 0 && Lp >= 6 && Lp <= 8 &&
         (long long)((a.n1 + 63) / 64) * ((a.n2 + 31) / 32) * a.nbatch >= 32)
         variant = 2;
     fused3_tile_shape(sizeof(T) == 8, inverse, ew != 1 ? 0 : variant, Lp, &TX, &TY, ew);
+    if (cplx_tall) TY = 32;
     bool use_y = false;                                   // float synthesis default: the pair-packed kernel and its tile
     if constexpr (sizeof(T) == 4) {
         use_y = inverse && dil == 1 && inv3y_plan_ok(p, Lp);   // (plane offsets stay below 2^32 bytes: checked there)
@@ -481,7 +485,7 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     if constexpr (sizeof(T) == 4) {
         if (rc == -1 && Lp > 12 && ew == 1) rc = launch_long3_f32(inverse, a, t, vec4, variant, td, s);
     }
-    if (rc == -1) rc = launch3<T>(inverse, a, t, vec4, ew != 1 ? 0 : variant, ew, td, s);
+    if (rc == -1) rc = launch3<T>(inverse, a, t, vec4, ew != 1 ? (cplx_tall ? 2 : 0) : variant, ew, td, s);
     prof_end(p, s, rc);
     if (rc == -1) return fail(NDWT_ERR_UNSUPPORTED, "no fused kernel instantiated for tap length %d", Lp);
     if (rc != 0) return fail(NDWT_ERR_HIP, "fused kernel launch failed: %s", hipGetErrorString((hipError_t)rc));

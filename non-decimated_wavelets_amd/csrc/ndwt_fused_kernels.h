@@ -175,6 +175,13 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
             default: return -1;                                           \
         }                                                                 \
     }                                                                     \
+    if (ew == 2 && variant == 2) {   /* interleaved complex on the tall tile */ \
+        switch (t.Lp) {                                                   \
+            NDWT_FUSED_CASE_C(Fwd3, false, T, 6, 2)                       \
+            NDWT_FUSED_CASE_C(Fwd3, false, T, 8, 2)                       \
+            default: break;                                               \
+        }                                                                 \
+    }                                                                     \
     if (ew == 2) {                                                        \
         switch (t.Lp) {                                                   \
             NDWT_FUSED_CASE_C(Fwd3, false, T, 2, 0)                       \
