@@ -451,6 +451,25 @@ def test_long_filters_complex(sizes, wn, precision, path):
     assert _relerr(w.rec(y).cpu().numpy(), x) < 20 * TOL[precision]
 
 
+@pytest.mark.parametrize("sizes,wn,cplx", [
+    ([512, 130, 12], "db4", False),                                    # 8 x 5 tall tiles, ragged in y, one short z chunk
+    ([260, 250, 9], ["db3", "db4", "db2"], False),                     # ragged in x and y
+    ([256, 130, 10], "db4", True),                                     # interleaved complex: 512 scalars per row
+    ([132, 250, 9], ["db3", "db2", "db4"], True),
+])
+def test_tall_analysis_tile_against_oracle(sizes, wn, cplx):
+    """float analysis with 6 / 8 taps takes the 64 x 32 tile with 1024 threads once the volume has 32 such tiles (real and
+    interleaved complex data); smaller volumes keep the 64 x 16 tile -- both against the oracle"""
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal(sizes) + (1j * rng.standard_normal(sizes) if cplx else 0)
+    w = ndwt.nd_dwt_3D(wn, sizes, "pres_l2_norm", 1, "precision", "single")
+    xg = _colmajor_gpu(x, "single")
+    y = w.dec(xg, 2)
+    wl = [wn] * 3 if isinstance(wn, str) else wn
+    assert _relerr(y.cpu().numpy(), orc.spatial_dec(x, wl, 2, 1)) <= TOL["single"]
+    assert _relerr(w.rec(y).cpu().numpy(), x) < 1e-5
+
+
 def test_properties_linearity_shift_adjoint():
     torch.manual_seed(0)
     sizes = [48, 36, 40]
