@@ -480,7 +480,13 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     prof_begin(p, inverse ? NDWT_KERNEL_FUSED_SYNTHESIS : NDWT_KERNEL_FUSED_ANALYSIS, s);
     int rc = -1;
     if constexpr (sizeof(T) == 4) {
-        if (use_y) rc = ew == 2 ? launch_inv3yc_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s) : launch_inv3y_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s);
+        if (use_y) {
+            rc = ew == 2 ? launch_inv3yc_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s) : launch_inv3y_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s);
+            if (rc == -1) {                               // the geometry above is this kernel's: never fall through to another one with it
+                prof_end(p, s, rc);
+                return fail(NDWT_ERR_UNSUPPORTED, "pair-packed synthesis kernel not instantiated for tap length %d", Lp);
+            }
+        }
     }
     if constexpr (sizeof(T) == 4) {
         if (rc == -1 && Lp > 12 && ew == 1) rc = launch_long3_f32(inverse, a, t, vec4, variant, td, s);
