@@ -494,6 +494,7 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     if (rc == -1) rc = launch3<T>(inverse, a, t, vec4, ew != 1 ? (cplx_tall ? 2 : 0) : variant, ew, td, s);
     prof_end(p, s, rc);
     if (rc == -1) return fail(NDWT_ERR_UNSUPPORTED, "no fused kernel instantiated for tap length %d", Lp);
+    if (rc == -2) return fail(NDWT_ERR_UNSUPPORTED, "internal: launch geometry (%d x %d tiles) does not match the kernel's tile shape", TX, TY);
     if (rc != 0) return fail(NDWT_ERR_HIP, "fused kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     return NDWT_OK;
 }

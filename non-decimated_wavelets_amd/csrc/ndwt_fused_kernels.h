@@ -29,6 +29,11 @@ __global__ __launch_bounds__(K::NT) __attribute__((amdgpu_waves_per_eu(K::WPE, K
 // taps_dev: device buffer holding Taps3<T, Lp> (lo[3][Lp] then hi[3][Lp]) for this direction
 template <class K> int launch_fused3(const typename K::Args& a, const FusedTapsD& t, const void* taps_dev, hipStream_t s) {
     (void)t;
+    // the host computed the tiling for a tile shape (fused3_tile_shape); this kernel was compiled for one: they must be the same,
+    // or workgroups would run off their tiles -- a status code here instead of a memory fault there
+    if (a.ntx != (a.n1 + K::TX - 1) / K::TX || a.nty != (a.n2 + K::TY - 1) / K::TY || a.zchunk < 1 ||
+        (long long)a.nzc * a.zchunk < a.n3 || (long long)(a.nzc - 1) * a.zchunk >= a.n3)
+        return -2;
     const int nblocks = a.ntx * a.nty * a.nzc * a.nbatch;
     hipLaunchKernelGGL(fused3_kernel<K>, dim3(nblocks), dim3(K::NT), 0, s, a, (const typename K::Taps*)taps_dev);
     return (int)hipGetLastError();
