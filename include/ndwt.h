@@ -105,10 +105,11 @@ int ndwt_dec(ndwt_plan* plan, const void* x_dev, void* y_dev, int level, void* s
 int ndwt_rec(ndwt_plan* plan, const void* y_dev, void* x_dev, int level, void* stream);
 /* The same with a PITCHED coefficient array: band b starts at y_dev + b * band_pitch elements (band_pitch >= prod(dims);
  * 0 = packed, i.e. ndwt_dec / ndwt_rec).  The packed layout is the reference's (a MATLAB array [dims, bands]); callers that
- * own the coefficient buffer (iterative solvers, the Python classes with 'band_pitch', ndwt_denoise's scratch) gain about 10 %
+ * own the coefficient buffer (iterative solvers, the Python classes with 'band_pitch', ndwt_denoise's scratch) gain 4 - 12 %
  * on the synthesis of power-of-two volumes by keeping the 2^d band streams a few hundred bytes off a power-of-two distance:
- * with every band at the same address modulo 2^29 the L2 misses of the 512^3 synthesis are 1.55x the bytes it needs, with
- * band_pitch = ndwt_band_pitch(plan) (prod(dims) + 256 bytes) 1.10x.  Results are identical. */
+ * with every band at the same address modulo 1 KiB the fabric traffic of the 512^3 synthesis is 1.23x its algorithmic bytes
+ * (1.44x before the library skewed the one band it owns, the approximation scratch), with band_pitch = ndwt_band_pitch(plan)
+ * (prod(dims) + 256 bytes) 1.08x.  Results are identical. */
 int ndwt_dec_pitched(ndwt_plan* plan, const void* x_dev, void* y_dev, int64_t band_pitch, int level, void* stream);
 int ndwt_rec_pitched(ndwt_plan* plan, const void* y_dev, int64_t band_pitch, void* x_dev, int level, void* stream);
 int64_t ndwt_band_pitch(const ndwt_plan* plan);   /* the recommended pitch in elements */
