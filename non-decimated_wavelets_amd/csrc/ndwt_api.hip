@@ -294,7 +294,7 @@ static bool fused3_eligible(const ndwt_plan* p, long long stride, int* Lp_out, i
     const int lmax = (p->dtype == NDWT_F32 && p->complexity == NDWT_REAL) ? (dir == 0 ? 20 : 16) : 12;
     // 18- and 20-tap synthesis exist as the pair-packed kernel only (uniform wavelets, or mixed ones with even padding on every axis)
     if (Lp > lmax && !(dir == 1 && Lp <= 20 && inv3y_plan_ok(p, Lp))) return false;
-    if (p->dtype == NDWT_F64 && Lp > 10) return false;   // double, db6: the fused kernels spill (6.7 ms vs 4.8 ms per-axis at 256^3)
+    if (p->dtype == NDWT_F64 && Lp > 12) return false;   // double: up to db6 (64x8 tiles with 512 threads keep 10 / 12 taps free of spills)
     // interleaved complex: the fused kernels with the x taps stepping over (re, im) pairs, tap lengths <= 8 (float: <= 12)
     if (p->complexity != NDWT_REAL && (Lp > (p->dtype == NDWT_F32 ? 12 : 8) || (p->dims[0] * 2) % 4 != 0)) return false;
     long long nbatch = p->ndim == 4 ? p->dims[3] + 64 : 1;
@@ -372,10 +372,10 @@ void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int
     if (ew != 1) variant = 0;
     *TX = 64;
     if (!inverse) {
-        *TY = f64 ? ((Lp >= 10 || (variant == 1 && Lp >= 6 && ew == 1) || (ew == 2 && Lp == 8)) ? 16 : 8) : 16;   // double, db5/db6, complex db4 (db3/db4: variant 1): 512 threads
+        *TY = f64 ? ((Lp == 10 || (variant == 1 && Lp >= 6 && Lp <= 8 && ew == 1) || (ew == 2 && Lp == 8)) ? 16 : 8) : 16;   // double: db5, complex db4 (db3/db4: variant 1) 64x16 with 512 threads; db6 64x8 with 512
         if (!f64 && ew == 1 && ((variant == 2 && Lp <= 8) || (variant != 1 && Lp >= 10 && Lp <= 16))) *TY = 32;   // float, tall tile: 10 .. 16 taps (<= 8: A/B)
     } else if (f64) {
-        *TY = (variant == 3 && Lp == 8) ? 8 : 16;                                 // lane-shift kernel 64x16; variant 3 = LDS kernel
+        *TY = ((variant == 3 && Lp == 8) || Lp >= 10) ? 8 : 16;                   // lane-shift kernel 64x16 (10 / 12 taps: 64x8); variant 3 = LDS kernel
     } else {
         *TY = (variant == 3 && Lp == 8) ? 16 : (ew == 4 ? 16 : 32);              // tall tile; x taps over 4 scalars: 64x16 / 512 threads
     }

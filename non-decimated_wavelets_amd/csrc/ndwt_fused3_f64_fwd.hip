@@ -25,7 +25,7 @@ int launch_fwd3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4,
         NDWT_FUSED_CASE(Fwd3, false, double, 6, 0)
         NDWT_FUSED_CASE(Fwd3, false, double, 8, 0)
         NDWT_FUSED_CASE(Fwd3, false, double, 10, 1)
-        NDWT_FUSED_CASE(Fwd3, false, double, 12, 1)
+        NDWT_FUSED_CASE(Fwd3, false, double, 12, 5)   // 64x8 tile, 512 threads: no spills (64x16 spills 137 registers)
         default: return -1;
     }
 }

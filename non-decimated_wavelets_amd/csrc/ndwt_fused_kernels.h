@@ -163,8 +163,8 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
         NDWT_FUSED_CASE(Inv3S, true, T, 4, 1)                             \
         NDWT_FUSED_CASE(Inv3S, true, T, 6, 1)                             \
         NDWT_FUSED_CASE(Inv3S, true, T, 8, 1)                             \
-        NDWT_FUSED_CASE(Inv3S, true, T, 10, 1)                            \
-        NDWT_FUSED_CASE(Inv3S, true, T, 12, 1)                            \
+        NDWT_FUSED_CASE(Inv3S, true, T, 10, 5)   /* 64x8 tile, 512 threads: no spills (64x16: 32 / 71 spilled registers) */ \
+        NDWT_FUSED_CASE(Inv3S, true, T, 12, 5)                            \
         default: return -1;                                               \
     }
 

@@ -24,6 +24,9 @@ template <int V> struct Fused3Tile<double, false, V> { static constexpr int TX =
 template <> struct Fused3Tile<double, false, 1>      { static constexpr int TX = 64, TY = 16, NT = 512, RY = 4, WPE = 2; };   // long filters (db5, db6)
 template <int V> struct Fused3Tile<double, true, V>  { static constexpr int TX = 64, TY = 8, NT = 256, RY = 4, WPE = 2; };
 template <> struct Fused3Tile<double, true, 1>       { static constexpr int TX = 64, TY = 16, NT = 512, RY = 2, WPE = 2; };   // lane-shift kernel (Inv3S): the double default
+// double, 10 / 12 taps: 64 x 8 tiles with 512 threads -- the only shapes that keep these windows in 256 registers without spills
+template <> struct Fused3Tile<double, false, 5>      { static constexpr int TX = 64, TY = 8, NT = 512, RY = 4, WPE = 2; };
+template <> struct Fused3Tile<double, true, 5>       { static constexpr int TX = 64, TY = 8, NT = 512, RY = 1, WPE = 2; };
 // float synthesis default (pair-packed kernel Inv3Y): 64 x 32 tile, 1024 threads, one workgroup per CU
 constexpr int kInv3YTX = 64, kInv3YTY = 32;
 // The pair-packed synthesis tile: the haloed rows (TY + L - 1) must fit the 16 waves of the workgroup at three rows per wave,

@@ -470,6 +470,28 @@ def test_tall_analysis_tile_against_oracle(sizes, wn, cplx):
     assert _relerr(w.rec(y).cpu().numpy(), x) < 1e-5
 
 
+@pytest.mark.parametrize("sizes,wn", [
+    ([64, 40, 36], "db5"),
+    ([68, 41, 30], "db6"),                                             # 64 x 8 tiles with 512 threads in both directions
+    ([70, 37, 33], ["db6", "db5", "db3"]),                             # scalar accesses, mixed wavelets
+])
+def test_long_filters_double(sizes, wn):
+    """fp64 with 10 / 12 taps on the fused kernels (spill-free 64 x 8 tiles)"""
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal(sizes)
+    w = ndwt.nd_dwt_3D(wn, sizes, "pres_l2_norm", 1, "precision", "double")
+    xg = _colmajor_gpu(x, "double")
+    y = w.dec(xg, 2)
+    assert list(w._plans.values())[0].describe() == "fused3d"
+    wl = [wn] * 3 if isinstance(wn, str) else wn
+    assert _relerr(y.cpu().numpy(), orc.spatial_dec(x, wl, 2, 1)) <= TOL["double"]
+    c = rng.standard_normal(sizes + [15])
+    got = w.rec(_colmajor_gpu(c, "double")).cpu().numpy()
+    want = orc.spatial_rec(c, wl, 1)
+    assert np.abs(got - want).max() <= TOL["double"] * max(np.abs(want).max(), np.abs(c).max())
+    assert _relerr(w.rec(y).cpu().numpy(), x) < 20 * TOL["double"]
+
+
 def test_properties_linearity_shift_adjoint():
     torch.manual_seed(0)
     sizes = [48, 36, 40]
@@ -553,10 +575,10 @@ def test_copy_free_slab_entry_points_and_sharded_driver_on_one_gpu():
     api = importlib.import_module("non-decimated_wavelets_amd.api")
     sh = importlib.import_module("non-decimated_wavelets_amd.sharded")
     n1, n2, n3 = 72, 40, 48
-    # plans on the per-axis path (double with db6 here) refuse the copy-free entry points instead of doing something else
-    p64 = api.Plan([n1, n2, 24], ["db6"] * 3, torch.float64, max_level=1)
+    # plans on the per-axis path (double with db7 here) refuse the copy-free entry points instead of doing something else
+    p64 = api.Plan([n1, n2, 24], ["db7"] * 3, torch.float64, max_level=1)
     assert p64.describe() == "axis"
-    dummy = torch.zeros(8, 24 + 11, n2, n1, device="cuda", dtype=torch.float64)
+    dummy = torch.zeros(8, 24 + 13, n2, n1, device="cuda", dtype=torch.float64)
     with pytest.raises(ndwt.NdwtError):
         p64.synthesis_level_slab_ext([dummy[b].data_ptr() for b in range(8)], dummy.data_ptr(), 1)
     for dtype, tol in ((torch.float32, 2e-6), (torch.float64, 1e-12)):

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""dec / rec time of fp64 volumes for db4 .. db6, fused vs per-axis.  python tools/bench_fp64_long.py [n]"""
+import importlib
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+api = importlib.import_module("non-decimated_wavelets_amd.api")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+level = 3
+for K in (4, 5, 6):
+    for generic in (False, True):
+        plan = api.Plan([n, n, n], [f"db{K}"] * 3, torch.float64, False, True, "reference", max_level=level)
+        plan.set_path(generic)
+        x = torch.randn(n, n, n, device="cuda", dtype=torch.float64)
+        y = torch.empty((api.num_bands(3, level), n, n, n), device="cuda", dtype=torch.float64)
+        r = torch.empty_like(x)
+        s = torch.cuda.current_stream().cuda_stream
+        for _ in range(2):
+            plan.dec(x.data_ptr(), y.data_ptr(), level, s); plan.rec(y.data_ptr(), r.data_ptr(), level, s)
+        torch.cuda.synchronize()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        for _ in range(5):
+            plan.dec(x.data_ptr(), y.data_ptr(), level, s)
+        e[1].record()
+        for _ in range(5):
+            plan.rec(y.data_ptr(), r.data_ptr(), level, s)
+        e[2].record()
+        torch.cuda.synchronize()
+        err = float(torch.linalg.vector_norm(r - x) / torch.linalg.vector_norm(x))
+        print(f"fp64 db{K} {n}^3 L{level} {'per-axis' if generic else plan.describe():9s} dec {e[0].elapsed_time(e[1]) / 5:7.3f} ms  "
+              f"rec {e[1].elapsed_time(e[2]) / 5:7.3f} ms  round trip {err:.1e}", flush=True)
