@@ -450,6 +450,9 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     if (!inverse && sizeof(T) == 4 && ew == 1 && variant == 0 && Lp >= 6 && Lp <= 8 &&
         (long long)((a.n1 + 63) / 64) * ((a.n2 + 31) / 32) * a.nbatch >= 32)
         variant = 2;
+    // double analysis, 6 and 8 taps: 64x16 tile with 512 threads, one column per thread (384^3 db4: 1.29 -> 0.97 ms per launch,
+    // 320^3 -15 %, 512^3 -2 %, 256^3 +2 %); NDWT_VARIANT_FWD=3 keeps the 64x8 tile with 256 threads
+    if (!inverse && sizeof(T) == 8 && ew == 1 && variant == 0 && Lp >= 6 && Lp <= 8) variant = 1;
     fused3_tile_shape(sizeof(T) == 8, inverse, ew != 1 ? 0 : variant, Lp, &TX, &TY, ew);
     if (cplx_tall) TY = 32;
     bool use_y = false;                                   // float synthesis default: the pair-packed kernel and its tile
