@@ -23,10 +23,11 @@ inline void fused3_geometry(Fused3Args<T>& a, int TX, int TY, int Lp, int target
     int want = (int)(target_blocks / per_chunk);
     int min_chunk = 4 * (Lp - 1);                 // prologue <= 25 % of the chunk
     if (min_chunk < 8) min_chunk = 8;
-    if (want < 1) {
-        // more tiles than resident slots: the launch runs in rounds of `target_blocks` workgroups and a partial last round costs
-        // a whole one (768^3 synthesis: 288 tiles on 256 CUs = 2 rounds of 775 planes, 5.6 ms; cut into 8 chunks = 9 full rounds
-        // of 103 planes, 3.6 ms).  Pick the chunk count with the fewest plane steps, a little in favour of fewer rounds.
+    if (want < 1 || per_chunk * want * 4 < (long long)target_blocks * 3) {
+        // More tiles than resident slots, or a single round that would leave more than a quarter of them empty (384^3 double
+        // synthesis: 144 tiles on 256 CUs): the launch runs in rounds of `target_blocks` workgroups and a partial last round
+        // costs a whole one (768^3 synthesis: 288 tiles on 256 CUs = 2 rounds of 775 planes, 5.6 ms; cut into 8 chunks = 9 full
+        // rounds of 103 planes, 3.6 ms).  Pick the chunk count with the fewest plane steps, a little in favour of fewer rounds.
         double best = 0.0;
         want = 1;
         const int max_chunks = a.n3 / min_chunk > 0 ? a.n3 / min_chunk : 1;
