@@ -35,6 +35,21 @@ def run(d):
     print(f"  Absolute max reconstruction error = {(x_recon - x).abs().max().item():.3e}")
 
 
+def extras():
+    """not in the reference: a solver-style loop on device tensors -- pitched coefficient tensors and thresholding on the GPU"""
+    sizes = [128, 128, 64]
+    x = torch.randn(*reversed(sizes), device="cuda").permute(2, 1, 0)
+    w = ndwt.nd_dwt_3D("db4", sizes, "pres_l2_norm", True, "precision", "single", "band_pitch", "auto")
+    y = w.dec(x, 3)                               # same shape / values as the packed array; bands 256 bytes further apart
+    y = w.shrink(y, 0.5, "soft")                  # detail bands only; returns a new (pitched) tensor
+    x1 = w.rec(y)
+    x2 = w.denoise(x, 3, 0.5, "soft")             # the same in one call, coefficients never leave the plan's scratch
+    print(f"3-D {sizes} db4 level 3, pitched coefficients: band stride {y.stride()[-1]} elements for {x.numel()} per band; "
+          f"|rec(shrink(dec(x))) - denoise(x)| = {(x1 - x2).abs().max().item():.1e}")
+
+
 if __name__ == "__main__":
     for d in ([int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]):
         run(d)
+    if len(sys.argv) == 1:
+        extras()
