@@ -23,7 +23,7 @@ int launch_inv3yc_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, 
         NDWT_INVYC_CASE(4, false)
         NDWT_INVYC_CASE(6, false)
         NDWT_INVYC_CASE(8, true)
-        NDWT_INVYC_CASE(10, true)
+        NDWT_INVYC_CASE(10, false)   // (two register sets: 1 spilled register)
         NDWT_INVYC_CASE(12, false)
         default: return -1;
     }
