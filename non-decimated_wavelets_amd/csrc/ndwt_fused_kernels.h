@@ -93,27 +93,10 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
         return vec4 ? launch_fused3<NDWT_FUSED_K(KIND, INV, T, LL, V, true)>(a, t, taps_dev, s)                        \
                     : launch_fused3<NDWT_FUSED_K(KIND, INV, T, LL, V, false)>(a, t, taps_dev, s);
 
-#define NDWT_FUSED_SWITCH_V(KIND, INV, T, V)  \
-    switch (t.Lp) {                            \
-        NDWT_FUSED_CASE(KIND, INV, T, 2, V)    \
-        NDWT_FUSED_CASE(KIND, INV, T, 4, V)    \
-        NDWT_FUSED_CASE(KIND, INV, T, 6, V)    \
-        NDWT_FUSED_CASE(KIND, INV, T, 8, V)    \
-        NDWT_FUSED_CASE(KIND, INV, T, 10, V)   \
-        NDWT_FUSED_CASE(KIND, INV, T, 12, V)   \
-        default: return -1;                    \
-    }
-
-// Default (variant 0): analysis = Fwd3; synthesis = lane-shift kernel Inv3S for float tap lengths <= 8 (db1..db4),
-// LDS kernel Inv3 otherwise.  Variants 1..3 are A/B alternatives for db4 (NDWT_VARIANT_FWD / NDWT_VARIANT_INV).
-#define NDWT_FUSED_SWITCH(KIND, KINDV, INV, T)                            \
-    if (variant == 1 && t.Lp == 8) { switch (t.Lp) { NDWT_FUSED_CASE(KINDV, INV, T, 8, 1) } }  \
-    if (variant == 2 && t.Lp == 8) { switch (t.Lp) { NDWT_FUSED_CASE(KINDV, INV, T, 8, 2) } }  \
-    if (variant == 3 && t.Lp == 8) { switch (t.Lp) { NDWT_FUSED_CASE(KIND, INV, T, 8, 3) } }   \
-    NDWT_FUSED_SWITCH_V(KIND, INV, T, 0)
-
-// float synthesis: the lane-shift kernel on a tall 64x32 tile (1024 threads, one workgroup per CU) is the default
-// (db6: 512 threads with two items each -- the 1024-thread form spills there); variant 3 = the LDS kernel (A/B, db4 only)
+// float synthesis other than the pair-packed kernel (ndwt_fused3_f32_invy*.hip, the default wherever it applies): the lane-shift
+// kernel Inv3S on a tall 64x32 tile (1024 threads, one workgroup per CU; db6: 512 threads with two items each -- the 1024-thread
+// form spills there) for mixed wavelets with odd tap padding, dilated levels and NDWT_VARIANT_INV=4; variant 3 = the LDS kernel
+// (A/B, db4 only)
 #define NDWT_FUSED_SWITCH_INV_F32(T)                                      \
     if (ew == 4) {                                                        \
         switch (t.Lp) {                                                   \

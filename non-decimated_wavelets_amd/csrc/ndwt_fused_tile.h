@@ -7,9 +7,9 @@ namespace ndwt {
 constexpr int kFused3Variants = 4;
 template <typename T, bool INVERSE, int V> struct Fused3Tile;
 // float, analysis
-template <> struct Fused3Tile<float, false, 0> { static constexpr int TX = 64, TY = 16, NT = 256, RY = 4, WPE = 3; };
-template <> struct Fused3Tile<float, false, 1> { static constexpr int TX = 64, TY = 16, NT = 512, RY = 4, WPE = 2; };   // long filters (db5, db6): one column per thread
-template <> struct Fused3Tile<float, false, 2> { static constexpr int TX = 64, TY = 32, NT = 1024, RY = 4, WPE = 4; };  // tall tile, A/B runs
+template <> struct Fused3Tile<float, false, 0> { static constexpr int TX = 64, TY = 16, NT = 256, RY = 4, WPE = 3; };   // db1, db2 and small volumes
+template <> struct Fused3Tile<float, false, 1> { static constexpr int TX = 64, TY = 16, NT = 512, RY = 4, WPE = 2; };   // one column per thread: 18 / 20 taps, complex data with 10 / 12 taps
+template <> struct Fused3Tile<float, false, 2> { static constexpr int TX = 64, TY = 32, NT = 1024, RY = 4, WPE = 4; };  // tall tile, one workgroup per CU: the default for 6 .. 16 taps on volumes with >= 32 such tiles
 template <> struct Fused3Tile<float, false, 3> { static constexpr int TX = 64, TY = 16, NT = 256, RY = 4, WPE = 3; };
 // float, synthesis
 template <> struct Fused3Tile<float, true, 0>  { static constexpr int TX = 64, TY = 16, NT = 256, RY = 2, WPE = 2; };
