@@ -24,6 +24,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s is the measured copy ceiling)
+TRAFFIC_PROFILE = "r02_traffic.json"   # committed rocprofv3 --pmc figures of the headline command (fallback when the live passes cannot run)
 KERNEL_NAMES = {0: "fused_analysis", 1: "fused_synthesis", 2: "axis_analysis", 3: "axis_synthesis"}
 
 
@@ -32,8 +33,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--ndim", type=int, default=3, choices=[3, 4])
-    ap.add_argument("--size", type=int, nargs="+", default=None, help="n1 n2 n3 [n4]; default 512^3 / 256^3 x 32")
+    ap.add_argument("--ndim", type=int, default=3, choices=[2, 3, 4])
+    ap.add_argument("--size", type=int, nargs="+", default=None, help="n1 n2 [n3 [n4]]; default 4096^2 / 512^3 / 256^3 x 32")
     ap.add_argument("--wname", default="db4")
     ap.add_argument("--level", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -42,11 +43,15 @@ def parse_args():
                     help="layout of the coefficient buffer between dec and rec: packed = the reference's; auto = ndwt_band_pitch()")
     ap.add_argument("--packed-only", action="store_true", help="skip the secondary pass with pitched coefficients (profiling runs: "
                     "both passes launch the same kernels, which a kernel-stats average would mix)")
+    ap.add_argument("--no-others", action="store_true", help="skip the `sustained` run and the `other_configs` (cfg2 / cfg4 / cfg5) that "
+                    "the default N=1 line carries after the headline's timed region")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not start the rocprofv3 --pmc child passes that measure "
+                    "roofline.traffic of the headline configuration (the committed profile's figure is reported instead)")
     ap.add_argument("--zchunk", type=int, default=0)
     ap.add_argument("--target-blocks", type=int, default=0)
     a = ap.parse_args()
     if a.size is None:
-        a.size = [512, 512, 512] if a.ndim == 3 else [256, 256, 256, 32]
+        a.size = {2: [4096, 4096], 3: [512, 512, 512], 4: [256, 256, 256, 32]}[a.ndim]
     if len(a.size) != a.ndim:
         ap.error(f"--size needs {a.ndim} numbers")
     return a
@@ -104,6 +109,110 @@ def cpu_baseline(level, wname, sample_sizes, workers):
     err = float(np.abs(r - x).max())
     assert err < 1e-9, err
     return float(np.prod(sample_sizes)) / dt / 1e6, dt
+
+
+def measure_config(api, torch, dev, d, sizes, wname, level, steps, warmup):
+    """One non-headline BASELINE configuration on this GPU, packed (reference) coefficient layout: wall-clock mean and hipEvent
+    median per dec+rec step, whole-step roofline fraction and the per-kernel HIP-event averages.  Runs AFTER the headline's
+    timed region; its buffers are released before it returns."""
+    import statistics
+    V = 1
+    for n in sizes:
+        V *= n
+    nbands = api.num_bands(d, level)
+    plan = api.Plan(sizes, [wname] * d, torch.float32, False, True, "reference", max_level=max(level, 3), device=dev.index)
+    x = torch.randn(tuple(reversed(sizes)), device=dev, dtype=torch.float32)
+    y = torch.empty(nbands * V, device=dev, dtype=torch.float32)
+    r = torch.empty_like(x)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        plan.dec(x.data_ptr(), y.data_ptr(), level, stream)
+        plan.rec(y.data_ptr(), r.data_ptr(), level, stream)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for e0, e1 in evs:
+        e0.record()
+        step()
+        e1.record()
+    torch.cuda.synchronize(dev)
+    med = statistics.median(e0.elapsed_time(e1) for e0, e1 in evs)
+    plan.set_profiling(True)
+    psteps = max(1, min(steps, 5))
+    for _ in range(psteps):
+        step()
+    torch.cuda.synchronize(dev)
+    prof = {k: plan.get_profile(k) for k in KERNEL_NAMES}
+    plan.set_profiling(False)
+    rt = float(torch.linalg.vector_norm((r - x).double()) / torch.linalg.vector_norm(x.double()))
+    step_bytes = 2 * level * (1 + (1 << d)) * V * 4
+    nb3 = 1 << min(d, 3)                                          # bands of one fused launch: 4 (2-D level), 8 (3-D level / one t-band of a 4-D level)
+    per_voxel = {0: 1 + nb3, 1: nb3 + 1, 2: 1 + 2, 3: 2 + 1}
+    kern = {}
+    for k, (tot, n) in prof.items():
+        if n:
+            avg = tot / n
+            kern[KERNEL_NAMES[k]] = {"avg_launch_ms": round(avg, 4), "launches_per_step": n // psteps,
+                                     "frac": round(per_voxel[k] * V * 4 / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    shape = "x".join(str(n) for n in sizes)
+    out = {"workload": f"{d}D fp32 {shape} {wname} {level} levels, dec+rec, packed (reference) coefficients", "path": plan.describe(),
+           "steps": steps, "ms_per_step": round(dt * 1e3, 4), "median_ms_per_step_hip_events": round(med, 4),
+           "value": round(V / dt / 1e6, 1), "unit": "Mvoxels/s", "algorithmic_bytes_per_step": step_bytes,
+           "whole_step_frac": round(step_bytes / dt / 1e9 / HBM_PEAK_GBS, 4), "kernels": kern, "roundtrip_rel_l2": rt}
+    del plan, x, y, r
+    torch.cuda.empty_cache()
+    return out
+
+
+def live_traffic(extra_args):
+    """HBM-side bytes per launch of the fused kernels of THIS command line, measured now: two child processes
+    `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --steps 2 --warmup 1 ...` (separate passes, the program directly after
+    `--`; MI355X_MICROARCH.md, HBM: bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB on gfx950).  None if rocprofv3 is missing or a pass fails."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    res = {}
+    tmp = tempfile.mkdtemp(prefix="ndwt_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = ["rocprofv3", "--pmc", c, "--output-format", "csv", "-d", os.path.join(tmp, c), "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--packed-only", "--no-others",
+                   "--no-live-traffic"] + extra_args
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            if r.returncode != 0:
+                return None
+            agg = collections.defaultdict(list)
+            for f in glob.glob(os.path.join(tmp, c, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    k = row["Kernel_Name"]
+                    if "ndwt" in k and row["Counter_Name"] == c:
+                        kind = "fused_synthesis" if "Inv" in k else "fused_analysis" if "Fwd" in k else "axis"
+                        agg[kind].append(float(row["Counter_Value"]))
+            for kind, v in agg.items():
+                res.setdefault(kind, {})[c] = sum(v) / len(v)
+        out = {}
+        for kind, v in res.items():
+            if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                out[kind] = {"FETCH_SIZE_KiB": round(v["FETCH_SIZE"]), "WRITE_SIZE_KiB": round(v["WRITE_SIZE"]),
+                             "traffic_bytes": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)}
+        return out or None
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -196,6 +305,16 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # ---- per-step HIP events (median of >= 20 iterations), a pass of its own: torch's current stream is the launch stream ----
+    import statistics
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    for e0, e1 in evs:
+        e0.record()
+        step()
+        e1.record()
+    torch.cuda.synchronize(dev)
+    median_ms = statistics.median(e0.elapsed_time(e1) for e0, e1 in evs)
+
     # ---- separate pass for the per-kernel figures: HIP events around every launch, on the launch stream ----
     prof_steps = max(1, min(a.steps, 10))
     plan.set_profiling(True)
@@ -224,7 +343,8 @@ def main():
     step_bytes = 2 * level * (1 + (1 << d)) * V * esize          # whole job, BASELINE.md section 3
     # dominant kernel = the kind with the largest total time; its algorithmic bytes per launch
     dom = max(prof, key=lambda k: prof[k][0])
-    per_voxel = {0: 1 + 8, 1: 8 + 1, 2: 1 + 2, 3: 2 + 1}       # volumes read + written per launch: fused 3-D level, one-axis pass
+    nb3 = 1 << min(d, 3)
+    per_voxel = {0: 1 + nb3, 1: nb3 + 1, 2: 1 + 2, 3: 2 + 1}   # volumes read + written per launch: fused 2-D / 3-D level, one-axis pass
 
     def kernel_row(k):
         tot_ms, n = prof[k]
@@ -245,16 +365,27 @@ def main():
     # HBM-side bytes per launch of the dominant kernel: FETCH_SIZE x 2 + WRITE_SIZE from separate rocprofv3 --pmc passes
     # of this command (MI355X_MICROARCH.md, HBM section), committed as profiles/r02_traffic.json -- null when this run is
     # not the profiled configuration
-    traffic, traffic_src = None, None
-    try:
-        if not sharded and d == 3 and sizes == [512, 512, 512] and a.wname == "db4" and level == 3 and not a.generic and a.band_pitch == "packed":
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+    traffic, traffic_src, traffic_all = None, None, None
+    headline_cfg = (not sharded and d == 3 and sizes == [512, 512, 512] and a.wname == "db4" and level == 3 and not a.generic and
+                    a.band_pitch == "packed" and a.zchunk == 0 and a.target_blocks == 0)
+    if not sharded and rank == 0 and not a.no_live_traffic and a.band_pitch == "packed":
+        # measured now, by two rocprofv3 --pmc child passes of this very command line (short: 2 steps)
+        passthrough = ["--ndim", str(d), "--size"] + [str(n) for n in sizes] + ["--wname", a.wname, "--level", str(level)]
+        if a.generic:
+            passthrough.append("--generic")
+        traffic_all = live_traffic(passthrough)
+        if traffic_all and drow["kernel"] in traffic_all:
+            traffic = traffic_all[drow["kernel"]]["traffic_bytes"]
+            traffic_src = "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this command (2 steps), (2*FETCH+WRITE) KiB per launch"
+    if traffic is None and headline_cfg:
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)))
             traffic = tj[drow["kernel"]]["traffic_bytes"]
-            traffic_src = "profiles/r02_traffic.json"
-    except Exception:
-        traffic = None
+            traffic_src = "profiles/" + TRAFFIC_PROFILE + " (committed profile of this command; not measured in this run)"
+        except Exception:
+            traffic = None
     roofline = {"bound": "hbm", "kernel": drow["kernel"], "achieved": drow["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": drow["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                "frac": drow["frac"], "traffic": traffic, "traffic_source": traffic_src, "traffic_all_kernels": traffic_all,
                 "algorithmic_bytes": drow["algorithmic_bytes"], "avg_launch_ms": drow["avg_launch_ms"], "launches": drow["launches"],
                 "other_kernels": [rows[k] for k in rows if k != dom and rows[k] is not None],
                 "whole_step_frac": round(step_bytes / (dt / a.steps) / 1e9 / (HBM_PEAK_GBS * world), 4)}
@@ -287,9 +418,9 @@ def main():
                    "roundtrip_rel_l2": float(torch.linalg.vector_norm((r - x).double()) / torch.linalg.vector_norm(x.double()))}
         try:
             if d == 3 and sizes == [512, 512, 512] and a.wname == "db4" and level == 3 and not a.generic:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+                tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)))
                 pitched["traffic"] = {k: tj["pitched"][k]["traffic_bytes"] for k in ("fused_synthesis", "fused_analysis")}
-                pitched["traffic_source"] = "profiles/r02_traffic.json"
+                pitched["traffic_source"] = "profiles/" + TRAFFIC_PROFILE
         except Exception:
             pass
 
@@ -297,25 +428,54 @@ def main():
     cube = f"{sizes[0]}^3" if d == 3 and len(set(sizes)) == 1 else shape
     out = {"metric": f"Mvoxels/s fwd+inv NDWT ({cube} fp32, {level} lvl {a.wname})", "value": round(value, 1), "unit": "Mvoxels/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
+           "median_ms_per_step_hip_events": round(median_ms, 4),
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"{d}D fp32 {shape} {a.wname} {level} levels, dec+rec, pres_l2_norm, reference dilation (stride 1)",
                       "sharding": "none" if world == 1 else f"outer-axis slabs x{world}; per level: analysis halo fetch (1 band) and synthesis "
                                                               f"scatter-add (1 band) via RCCL send/recv, overlapped with the interior planes",
-                      "path": "per-axis" if a.generic else ("fused3d" if d == 3 else "t-axis march + fused3d"),
+                      "path": "per-axis" if a.generic else plan.describe(),
                       "coefficient_layout": ("pitched local slabs owned by the sharded driver" if sharded else
                                              "packed (reference)" if a.band_pitch == "packed" else "pitched bands (ndwt_band_pitch)")},
            "roofline": roofline, "roundtrip_rel_l2": rt_err}
     if pitched is not None:
         out["pitched_coefficients"] = pitched
+    # ---- after the headline: a sustained run of the same step and the other single-GPU BASELINE configurations ----
+    if not sharded and headline_cfg and not a.no_others:
+        lay["pitch"], lay["y"] = 0, None
+        y = None
+        torch.cuda.empty_cache()
+        lay["y"] = torch.empty(nbands * V, device=dev, dtype=torch.float32)
+        step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(500):
+            step()
+        fence()
+        dts = (time.perf_counter() - t0) / 500
+        out["sustained"] = {"steps": 500, "ms_per_step": round(dts * 1e3, 4), "value": round(V / dts / 1e6, 1),
+                            "whole_step_frac": round(step_bytes / dts / 1e9 / HBM_PEAK_GBS, 4)}
+        lay["y"] = None
+        del x, r
+        torch.cuda.empty_cache()
+        others = {}
+        for name, (dd, ss, wn, lv, st) in {"cfg2": (2, [4096, 4096], "db4", 3, 50), "cfg4_transform": (3, [512, 512, 512], "db6", 4, 20),
+                                           "cfg5": (4, [256, 256, 256, 32], "db4", 3, 5)}.items():
+            try:
+                others[name] = measure_config(api, torch, dev, dd, ss, wn, lv, st, 3)
+            except Exception as e:                                # (a box with less free memory than cfg5's 100 GB: say so, keep the line)
+                others[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        out["other_configs"] = others
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cores = os.cpu_count() or 1
         workers = min(cores, 16)
-        if d == 3:
+        if d == 2:
+            sample = [4096, 4096] if cores >= 16 else [2048, 2048]
+        elif d == 3:
             sample = [512, 512, 128] if cores >= 16 else [192, 192, 128]
         else:
             sample = [128, 128, 64, 32] if cores >= 16 else [64, 64, 32, 32]
         v, secs = cpu_baseline(level, a.wname, sample, workers)
-        out["cpu_baseline"] = {"value": round(v, 2), "unit": "Mvoxels/s", "cores": workers, "kind": "port",
+        out["cpu_baseline"] = {"value": round(v, 2), "unit": "Mvoxels/s", "cores": workers, "host_cpu_count": cores, "kind": "port",
                                "sample": f"{'x'.join(map(str, sample))} fp64/complex128 {a.wname} {level} levels dec+rec, FFT-domain "
                                          f"restatement of mex/nddwt.c with scipy.fft workers={workers}; {secs:.1f} s"}
     if rank == 0:

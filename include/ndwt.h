@@ -89,6 +89,10 @@ int ndwt_plan_describe(const ndwt_plan* plan, char* buf, int buflen);
 /* tuning hook (tests, benchmarks): workgroup count the fused kernels aim for and/or a forced number of
  * outer-axis planes per workgroup; 0 restores the default.  Results never depend on it. */
 int ndwt_plan_set_tuning(ndwt_plan* plan, int target_blocks, int force_zchunk);
+/* test / tuning hook of tools/ (interleaved A/B runs): kernel variant per direction, marched chunk per direction, fp64 on the
+ * fused (1) or per-axis (0) kernels.  Negative = leave unchanged.  Every variant computes the same values; the library never
+ * reads the environment. */
+int ndwt_plan_set_variant(ndwt_plan* plan, int variant_fwd, int variant_inv, int zchunk_fwd, int zchunk_inv, int fp64_fused);
 /* per-kernel timing with HIP events recorded on the launch stream around every kernel this plan launches
  * (what bench.py's roofline line is computed from).  ndwt_plan_get_profile() synchronises the device, sums and
  * clears the records of one kernel kind. */

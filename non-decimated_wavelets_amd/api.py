@@ -69,6 +69,18 @@ class Plan:
     def set_tuning(self, target_blocks=0, force_zchunk=0):
         L.check(L.lib().ndwt_plan_set_tuning(self._h, int(target_blocks), int(force_zchunk)))
 
+    def set_variant(self, fwd=-1, inv=-1, zchunk_fwd=-1, zchunk_inv=-1, fp64_fused=-1):
+        """tuning hook of tools/ (A/B runs of kernel variants; same values): negative = unchanged"""
+        L.check(L.lib().ndwt_plan_set_variant(self._h, int(fwd), int(inv), int(zchunk_fwd), int(zchunk_inv), int(fp64_fused)))
+        return self
+
+    def set_variant_from_env(self):
+        """tools/ only: NDWT_VARIANT_FWD / NDWT_VARIANT_INV / NDWT_ZCHUNK_FWD / NDWT_ZCHUNK_INV / NDWT_FP64_FUSED of the caller's
+        environment, applied through set_variant (the library itself never reads the environment)"""
+        import os
+        g = lambda k: int(os.environ[k]) if os.environ.get(k) not in (None, "") else -1
+        return self.set_variant(g("NDWT_VARIANT_FWD"), g("NDWT_VARIANT_INV"), g("NDWT_ZCHUNK_FWD"), g("NDWT_ZCHUNK_INV"), g("NDWT_FP64_FUSED"))
+
     def set_profiling(self, on: bool):
         L.check(L.lib().ndwt_plan_set_profiling(self._h, int(bool(on))))
 

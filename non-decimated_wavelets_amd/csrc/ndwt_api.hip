@@ -476,7 +476,9 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
         a.in_bstride = a.out_bstride = p->dims[0];                         // sub-lattice offset along y ...
         a.in_bstride2 = a.out_bstride2 = p->dims[0] * p->dims[1];          // ... and along z
     }
-    a.nt = nt_store_ok<T>(a.rs, a.plane, out_bstride, out, nout);
+    // (a tile narrower than whole lines -- the 48-wide pair-packed tiles of 20 taps / complex 12 taps -- would put tile edges inside
+    // a line: two workgroups' partial nontemporal stores of one line, the read-modify-write case again)
+    a.nt = ((long long)TX * (long long)sizeof(T)) % 128 == 0 ? nt_store_ok<T>(a.rs, a.plane, out_bstride, out, nout) : 0;
     FusedTapsD t = fused_taps(p, Lp, inverse);
     const void* td = p->taps_dev[inverse ? 1 : 0];
     if (!td) return fail(NDWT_ERR_UNSUPPORTED, "plan has no device tap table");
@@ -916,11 +918,6 @@ static int plan_create_impl(ndwt_plan** plan, int ndim, const int64_t* dims, lon
     p->prof = new std::vector<ProfRec>();
     p->ev_pool = new std::vector<hipEvent_t>();
     p->fp64_fused = 1;   // measured: 256^3 fp64 db4 L3 2.5 ms fused (LDS analysis + lane-shift synthesis) vs 4.1 ms per-axis
-    if (const char* v = getenv("NDWT_FP64_FUSED")) p->fp64_fused = atoi(v);
-    if (const char* v = getenv("NDWT_VARIANT_FWD")) p->variant_fwd = atoi(v);
-    if (const char* v = getenv("NDWT_VARIANT_INV")) p->variant_inv = atoi(v);
-    if (const char* v = getenv("NDWT_ZCHUNK_FWD")) p->zchunk_dir[0] = atoi(v);
-    if (const char* v = getenv("NDWT_ZCHUNK_INV")) p->zchunk_dir[1] = atoi(v);
     static const char* ordn[4] = {"First", "Second", "Third", "Fourth"};
     p->vol = p->comp;
     for (int a = 0; a < ndim; ++a) {
@@ -1074,6 +1071,19 @@ int ndwt_plan_set_tuning(ndwt_plan* p, int target_blocks, int force_zchunk) {
     if (!p) return fail(NDWT_ERR_INVALID_ARG, "null plan");
     p->target_blocks = target_blocks > 0 ? target_blocks : 0;
     p->force_zchunk = force_zchunk > 0 ? force_zchunk : 0;
+    return NDWT_OK;
+}
+
+// test/tuning hook (tools/: interleaved A/B runs): kernel variants and per-direction march chunks of the fused kernels; every
+// variant computes the same values.  A negative argument leaves that setting as it is.  Nothing in the library reads the
+// environment: a plan behaves the same whatever the caller's process has exported.
+int ndwt_plan_set_variant(ndwt_plan* p, int variant_fwd, int variant_inv, int zchunk_fwd, int zchunk_inv, int fp64_fused) {
+    if (!p) return fail(NDWT_ERR_INVALID_ARG, "null plan");
+    if (variant_fwd >= 0) p->variant_fwd = variant_fwd;
+    if (variant_inv >= 0) p->variant_inv = variant_inv;
+    if (zchunk_fwd >= 0) p->zchunk_dir[0] = zchunk_fwd;
+    if (zchunk_inv >= 0) p->zchunk_dir[1] = zchunk_inv;
+    if (fp64_fused >= 0) p->fp64_fused = fp64_fused ? 1 : 0;
     return NDWT_OK;
 }
 

@@ -11,7 +11,7 @@ api = importlib.import_module("non-decimated_wavelets_amd.api")
 ycs = [int(v) for v in sys.argv[1].split(",")]
 n1 = n2 = 4096
 level = 3
-plan = api.Plan([n1, n2], ["db4", "db4"], torch.float32, False, True, "reference", max_level=3)
+plan = api.Plan([n1, n2], ["db4", "db4"], torch.float32, False, True, "reference", max_level=3).set_variant_from_env()
 x = torch.randn(n2, n1, device="cuda")
 y = torch.empty(10, n2, n1, device="cuda")
 r = torch.empty_like(x)

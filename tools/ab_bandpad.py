@@ -10,7 +10,7 @@ sys.path.insert(0, ".")
 api = importlib.import_module("non-decimated_wavelets_amd.api")
 n = 512
 vol = n ** 3
-plan = api.Plan([n, n, n], ["db4"] * 3, torch.float32, False, True, "reference", max_level=1)
+plan = api.Plan([n, n, n], ["db4"] * 3, torch.float32, False, True, "reference", max_level=1).set_variant_from_env()
 ab, aa, sb, sa = plan.slab_halo(1)
 pads = [0, 1024, 16 * 1024 + 256, 256 * 1024 + 1024, 1024 * 1024 + 4096, 3 * 1024 * 1024 + 17 * 1024]   # elements
 big = torch.randn(8 * (vol + max(pads)) + 1024, device="cuda")

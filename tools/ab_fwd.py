@@ -13,7 +13,7 @@ which = sys.argv[1]
 zcs = [int(v) for v in sys.argv[2].split(",")]
 n3 = int(sys.argv[3]) if len(sys.argv) > 3 else 512
 dims, level = [512, 512, n3], 3
-plan = api.Plan(dims, ["db4"] * 3, torch.float32, False, True, "reference", max_level=level)
+plan = api.Plan(dims, ["db4"] * 3, torch.float32, False, True, "reference", max_level=level).set_variant_from_env()
 nb = api.num_bands(3, level)
 x = torch.randn(n3, 512, 512, device="cuda")
 y = torch.empty((nb, n3, 512, 512), device="cuda")

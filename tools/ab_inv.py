@@ -18,7 +18,7 @@ level = 3
 plans = {}
 for v in variants:
     os.environ["NDWT_VARIANT_INV"] = str(v)
-    plans[v] = api.Plan([n, n, n], [wname] * 3, torch.float32, False, True, "reference", max_level=level)
+    plans[v] = api.Plan([n, n, n], [wname] * 3, torch.float32, False, True, "reference", max_level=level).set_variant_from_env()
 nb = api.num_bands(3, level)
 y = torch.randn((nb, n, n, n), device="cuda")
 s = torch.cuda.current_stream().cuda_stream

@@ -13,7 +13,7 @@ DIMS = [[int(v) for v in os.environ["DIMS"].split("x")]] if "DIMS" in os.environ
 ZCS = [int(v) for v in os.environ["ZCS"].split(",")] if "ZCS" in os.environ else (0, 2, 3, 4, 5, 7, 10, 14)
 for dims in DIMS:
     d, level = len(dims), 3
-    plan = api.Plan(dims, ["db4"] * d, torch.float32, False, True, "reference", max_level=level)
+    plan = api.Plan(dims, ["db4"] * d, torch.float32, False, True, "reference", max_level=level).set_variant_from_env()
     nb = api.num_bands(d, level)
     shp = tuple(reversed(dims))
     x = torch.randn(*shp, device="cuda")

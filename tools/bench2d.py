@@ -12,7 +12,7 @@ api = importlib.import_module("non-decimated_wavelets_amd.api")
 n1 = n2 = 4096
 level = 3
 for generic, pitched in ((False, False), (False, True), (True, False)):
-    plan = api.Plan([n1, n2], ["db4", "db4"], torch.float32, False, True, "reference", max_level=3)
+    plan = api.Plan([n1, n2], ["db4", "db4"], torch.float32, False, True, "reference", max_level=3).set_variant_from_env()
     plan.set_path(generic)
     bp = plan.band_pitch() if pitched else 0
     x = torch.randn(n2, n1, device="cuda")

@@ -13,7 +13,7 @@ dims = [int(v) for v in (sys.argv[1:5] if len(sys.argv) >= 5 else (128, 128, 128
 level = 3
 n1, n2, n3, n4 = dims
 V = n1 * n2 * n3 * n4
-plan = api.Plan(dims, ["db4"] * 4, torch.float32, False, True, "reference", max_level=level)
+plan = api.Plan(dims, ["db4"] * 4, torch.float32, False, True, "reference", max_level=level).set_variant_from_env()
 nb = api.num_bands(4, level)
 x = torch.randn(n4, n3, n2, n1, device="cuda")
 y = torch.empty(nb, n4, n3, n2, n1, device="cuda")

@@ -12,7 +12,7 @@ api = importlib.import_module("non-decimated_wavelets_amd.api")
 for dims, dtype, cplx in (([1 << 24], torch.float32, False), ([1 << 24], torch.float64, False), ([1 << 23], torch.float64, True),
                           ([4096, 4096], torch.float32, True), ([4096, 4096], torch.float64, False)):
     d, level = len(dims), 3
-    plan = api.Plan(dims, ["db4"] * d, dtype, cplx, True, "reference", max_level=level)
+    plan = api.Plan(dims, ["db4"] * d, dtype, cplx, True, "reference", max_level=level).set_variant_from_env()
     nb = api.num_bands(d, level)
     shp = tuple(reversed(dims)) + ((2,) if cplx else ())
     x = torch.randn(*shp, device="cuda", dtype=dtype)

@@ -11,7 +11,7 @@ api = importlib.import_module("non-decimated_wavelets_amd.api")
 for dims in ([512, 512, 512], [256, 256, 256], [4096, 4096]):
     d, level = len(dims), 3
     for generic in (False, True):
-        plan = api.Plan(dims, ["db4"] * d, torch.float32, False, True, "atrous", max_level=level)
+        plan = api.Plan(dims, ["db4"] * d, torch.float32, False, True, "atrous", max_level=level).set_variant_from_env()
         plan.set_path(generic)
         nb = api.num_bands(d, level)
         shp = tuple(reversed(dims))

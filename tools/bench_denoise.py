@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, ".")
 api = importlib.import_module("non-decimated_wavelets_amd.api")
 n, level = 512, 3
-plan = api.Plan([n, n, n], ["db4"] * 3, torch.float32, False, True, "reference", max_level=level)
+plan = api.Plan([n, n, n], ["db4"] * 3, torch.float32, False, True, "reference", max_level=level).set_variant_from_env()
 nb = api.num_bands(3, level)
 x = torch.randn(n, n, n, device="cuda")
 y = torch.empty((nb, n, n, n), device="cuda")

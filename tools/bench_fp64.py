@@ -13,7 +13,7 @@ api = importlib.import_module("non-decimated_wavelets_amd.api")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 wname = sys.argv[2] if len(sys.argv) > 2 else "db4"
 dims, level, K = [n, n, n], 3, 5
-plan = api.Plan(dims, [wname] * 3, torch.float64, False, True, "reference", max_level=level)
+plan = api.Plan(dims, [wname] * 3, torch.float64, False, True, "reference", max_level=level).set_variant_from_env()
 nb = api.num_bands(3, level)
 x = torch.randn(n, n, n, device="cuda", dtype=torch.float64)
 y = torch.empty((nb, n, n, n), device="cuda", dtype=torch.float64)

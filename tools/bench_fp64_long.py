@@ -11,7 +11,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 level = 3
 for K in (4, 5, 6):
     for generic in (False, True):
-        plan = api.Plan([n, n, n], [f"db{K}"] * 3, torch.float64, False, True, "reference", max_level=level)
+        plan = api.Plan([n, n, n], [f"db{K}"] * 3, torch.float64, False, True, "reference", max_level=level).set_variant_from_env()
         plan.set_path(generic)
         x = torch.randn(n, n, n, device="cuda", dtype=torch.float64)
         y = torch.empty((api.num_bands(3, level), n, n, n), device="cuda", dtype=torch.float64)

@@ -12,7 +12,7 @@ api = importlib.import_module("non-decimated_wavelets_amd.api")
 
 
 def run(name, dims, dtype, cplx, dilation, level=3, K=5, pitched=False, wname="db4"):
-    plan = api.Plan(dims, [wname] * len(dims), dtype, cplx, True, dilation, max_level=level)
+    plan = api.Plan(dims, [wname] * len(dims), dtype, cplx, True, dilation, max_level=level).set_variant_from_env()
     nb = api.num_bands(len(dims), level)
     bp = plan.band_pitch() if pitched else 0
     shp = tuple(reversed(dims)) + ((2,) if cplx else ())

@@ -14,7 +14,7 @@ level = 3
 for arg in sys.argv[3:]:
     dims = [int(v) for v in arg.split("x")] if "x" in arg else [int(arg)] * 3          # n or n1xn2xn3
     n = "x".join(str(v) for v in dims)
-    plan = api.Plan(dims, ["db4"] * 3, dt, cplx, True, "reference", max_level=level)
+    plan = api.Plan(dims, ["db4"] * 3, dt, cplx, True, "reference", max_level=level).set_variant_from_env()
     shp = tuple(reversed(dims)) + ((2,) if cplx else ())
     x = torch.randn(*shp, device="cuda", dtype=dt)
     y = torch.empty((api.num_bands(3, level),) + shp, device="cuda", dtype=dt)

@@ -10,7 +10,7 @@ sys.path.insert(0, ".")
 api = importlib.import_module("non-decimated_wavelets_amd.api")
 for dims in ([4096], [256, 256], [512, 512], [64, 64, 64], [128, 128, 128], [32, 32, 16, 16]):
     d, level = len(dims), 3
-    plan = api.Plan(dims, ["db4"] * d, torch.float32, False, True, "reference", max_level=level)
+    plan = api.Plan(dims, ["db4"] * d, torch.float32, False, True, "reference", max_level=level).set_variant_from_env()
     nb = api.num_bands(d, level)
     shp = tuple(reversed(dims))
     x = torch.randn(*shp, device="cuda")

@@ -17,7 +17,7 @@ r = torch.empty_like(x)
 s = torch.cuda.current_stream().cuda_stream
 for K in orders:
     for generic in (False, True):
-        plan = api.Plan([n, n, n], [f"db{K}"] * 3, torch.float32, False, True, "reference", max_level=level)
+        plan = api.Plan([n, n, n], [f"db{K}"] * 3, torch.float32, False, True, "reference", max_level=level).set_variant_from_env()
         plan.set_path(generic)
         for _ in range(2):
             plan.dec(x.data_ptr(), y.data_ptr(), level, s)

@@ -27,7 +27,7 @@ for case in cases:
     os.environ["NDWT_EXP_BANDMASK"] = str(case[2]) if len(case) > 2 else "0"
     os.environ["NDWT_EXP_BANDPAD"] = str(pad)
     os.environ["NDWT_EXP_BANDDIV"] = str(div)
-    plan = api.Plan([n, n, n], ["db4"] * 3, torch.float32, False, True, "reference", max_level=level)
+    plan = api.Plan([n, n, n], ["db4"] * 3, torch.float32, False, True, "reference", max_level=level).set_variant_from_env()
     for _ in range(3):
         plan.dec(x.data_ptr(), y.data_ptr(), level, s)
         plan.rec(y.data_ptr(), r.data_ptr(), level, s)

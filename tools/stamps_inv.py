@@ -18,7 +18,7 @@ if len(sys.argv) > 3:
     os.environ["NDWT_VARIANT_INV"] = sys.argv[3]
 wname = sys.argv[1] if len(sys.argv) > 1 else "db4"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 512
-plan = api.Plan([n, n, n], [wname] * 3, torch.float32, False, True, "reference", max_level=1)
+plan = api.Plan([n, n, n], [wname] * 3, torch.float32, False, True, "reference", max_level=1).set_variant_from_env()
 y = torch.randn(8, n, n, n, device="cuda")
 x = torch.empty(n, n, n, device="cuda")
 s = torch.cuda.current_stream().cuda_stream

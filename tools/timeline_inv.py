@@ -16,7 +16,7 @@ sys.path.insert(0, ".")
 api = importlib.import_module("non-decimated_wavelets_amd.api")
 L = importlib.import_module("non-decimated_wavelets_amd._lib")
 n = 512
-plan = api.Plan([n, n, n], ["db4"] * 3, torch.float32, False, True, "reference", max_level=1)
+plan = api.Plan([n, n, n], ["db4"] * 3, torch.float32, False, True, "reference", max_level=1).set_variant_from_env()
 y = torch.randn(8, n, n, n, device="cuda")
 x = torch.empty(n, n, n, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
