@@ -373,7 +373,7 @@ void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int
     *TX = 64;
     if (!inverse) {
         *TY = f64 ? ((Lp == 10 || (variant == 1 && Lp >= 6 && Lp <= 8 && ew == 1) || (ew == 2 && Lp == 8)) ? 16 : 8) : 16;   // double: db5, complex db4 (db3/db4: variant 1) 64x16 with 512 threads; db6 64x8 with 512
-        if (!f64 && ew == 1 && ((variant == 2 && Lp <= 8) || (variant != 1 && Lp >= 10 && Lp <= 16))) *TY = 32;   // float, tall tile: 10 .. 16 taps (<= 8: A/B)
+        if (!f64 && ew == 1 && (((variant == 2 || variant == 6) && Lp <= 8) || (variant != 1 && Lp >= 10 && Lp <= 16))) *TY = 32;   // float, tall tile: 10 .. 16 taps (<= 8: A/B)
     } else if (f64) {
         *TY = ((variant == 3 && Lp == 8) || Lp >= 10) ? 8 : 16;                   // lane-shift kernel 64x16 (10 / 12 taps: 64x8); variant 3 = LDS kernel
     } else {

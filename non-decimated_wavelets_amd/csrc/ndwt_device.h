@@ -1100,13 +1100,18 @@ template <typename T, int L> struct Taps3Y {             // the first two member
 
 // EW = 2: interleaved complex data.  A pair of adjacent scalars is then the (re, im) of one element and takes ONE tap, so the x
 // stage has the form of the y and z stages (a broadcast tap per packed FMA) and the (t[k], t[k-1]) tap pairs are not used.
-template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 4, int DEPTH_ = 1, int EW_ = 1> struct Inv3Y {
+// ZLDS_ > 0: that many of the L pending z sums of a thread live in LDS instead of registers (each is read, updated and written
+// back once per plane by its own thread: no barrier) -- what lets 12 taps keep two register sets of band loads inside the 128
+// registers of a 1024-thread workgroup without spills.
+template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 4, int DEPTH_ = 1, int EW_ = 1, int ZLDS_ = 0> struct Inv3Y {
     static_assert(sizeof(T) == 4, "pair-packed synthesis: float only (v_pk_fma_f32)");
     static_assert(EW_ == 1 || EW_ == 2, "real or interleaved complex data");
     static constexpr int L = L_, TX = TX_, TY = TY_, NT = NT_, WPE = WPE_, EW = EW_;
     static constexpr bool VEC4 = VEC4_;
     static constexpr int DEPTH = DEPTH_;                 // register sets of band loads per lane (planes in flight)
     static_assert(DEPTH == 1 || DEPTH == 2, "one or two register sets");
+    static constexpr int ZLDS = ZLDS_;                   // pending z sums kept in LDS (slots L - ZLDS .. L - 1)
+    static_assert(ZLDS >= 0 && ZLDS < L_, "at least one pending z sum stays in registers");
     static constexpr int NE = VEC4 ? 1 : 4;
     static constexpr int LH = L / 2, RH = L / 2 - 1;
     static constexpr int GL = (LH * EW + 3) / 4, GR = (RH * EW + 3) / 4;
@@ -1133,9 +1138,10 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
 
     struct Shared {
         chunk xs[2][2][NR][TXC];   // [buffer][y-bit][row][x pair] of (z-bit 0: x0, x1 | z-bit 1: x0, x1)
+        v2 zl[ZLDS ? ZLDS : 1][ZLDS ? NYI * NT : 1];   // [slot][item]: the pending z sums that do not live in registers
     };
     struct State {
-        v2 zacc[NYI][L];           // z-synthesis in scatter form: partial sums of the next L output planes (x0, x1), rotating
+        v2 zacc[NYI][L - ZLDS];    // z-synthesis in scatter form: partial sums of the next L output planes (x0, x1), rotating
         v4 raw[DEPTH][NRND][8];    // 4 x of every band of this lane's row(s); DEPTH 2: the set index is the plane's parity
         unsigned off[NRND][NE];    // BYTE offsets inside a plane (kNoRow: this lane holds no row and loads nothing)
         v2 P[NYI][2];              // y-synthesised (x0, x1) pairs of the newest plane: z-low / z-high inputs of the z stage
@@ -1415,20 +1421,29 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
 
     // z-synthesis in scatter form (rotation R as in Inv3S) and the store of the plane it completes
     template <int R>
-    static NDWT_DEV void zsyn(State& st, const RegTaps& tp, const Args& a, long long obase, int z, bool emit, int tid) {
+    static NDWT_DEV void zsyn(State& st, Shared& sh, const RegTaps& tp, const Args& a, long long obase, int z, bool emit, int tid) {
         NDWT_SFOR(k, NYI)
             const int it = tid + k * NT;
             if (it < YITEMS) {
                 const v2 P0 = st.P[k][0], P1 = st.P[k][1];
+                v2 o = (v2)(T(0));                       // the sum that tap L-1 completes: output plane z
                 NDWT_SFOR(j, L)
                     constexpr int slot = ((R - 1 - j) % L + L) % L;
-                    if constexpr (j == 0) st.zacc[k][slot] = (v2)(T(0));
-                    tap_fma<j, false>(st.zacc[k][slot], P0, tp.zl);
-                    tap_fma<j, true>(st.zacc[k][slot], P1, tp.zl);
+                    if constexpr (slot < L - ZLDS) {
+                        if constexpr (j == 0) st.zacc[k][slot] = (v2)(T(0));
+                        tap_fma<j, false>(st.zacc[k][slot], P0, tp.zl);
+                        tap_fma<j, true>(st.zacc[k][slot], P1, tp.zl);
+                        if constexpr (j == L - 1) o = st.zacc[k][slot];
+                    } else {
+                        v2 acc = (v2)(T(0));
+                        if constexpr (j != 0) acc = sh.zl[slot - (L - ZLDS)][it];
+                        tap_fma<j, false>(acc, P0, tp.zl);
+                        tap_fma<j, true>(acc, P1, tp.zl);
+                        if constexpr (j == L - 1) o = acc;
+                        else sh.zl[slot - (L - ZLDS)][it] = acc;
+                    }
                 NDWT_SEND
                 if (emit && st.ostore[k]) {
-                    constexpr int done = ((R - L) % L + L) % L;
-                    const v2 o = st.zacc[k][done];
                     T* dst = a.out[0] + obase + (long long)z * a.plane;   // wave-uniform
                     if constexpr (VEC4) {
                         gstore<v2>(dst, st.ooff[k], o, a.nt);
@@ -1441,10 +1456,10 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
         NDWT_SEND
     }
     template <int R>
-    static NDWT_DEV void zdispatch(int r, State& st, const RegTaps& tp, const Args& a, long long obase, int z, bool emit, int tid) {
+    static NDWT_DEV void zdispatch(int r, State& st, Shared& sh, const RegTaps& tp, const Args& a, long long obase, int z, bool emit, int tid) {
         if constexpr (R < L) {
-            if (r == R) zsyn<R>(st, tp, a, obase, z, emit, tid);
-            else zdispatch<R + 1>(r, st, tp, a, obase, z, emit, tid);
+            if (r == R) zsyn<R>(st, sh, tp, a, obase, z, emit, tid);
+            else zdispatch<R + 1>(r, st, sh, tp, a, obase, z, emit, tid);
         }
     }
 
@@ -1481,7 +1496,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
             ex.each([&](int tid, State& st) __attribute__((always_inline)) { ysyn(st, sh, tp, p & 1, tid); });
             NDWT_TL(3)
             ex.each([&](int tid, State& st) __attribute__((always_inline)) {
-                zdispatch<0>((p + 1) % L, st, tp, a, obase, tc.zbeg + s, s >= 0, tid);
+                zdispatch<0>((p + 1) % L, st, sh, tp, a, obase, tc.zbeg + s, s >= 0, tid);
             });
             NDWT_SETPRIO(0);
             NDWT_TL(4)

@@ -3,15 +3,16 @@
 namespace ndwt {
 
 template <int LL, bool V, int DEPTH> static int go(const Fused3Args<float>& a, const void* taps_dev, hipStream_t s) {
-    typedef Inv3Y<float, LL, inv3y_tx(LL), inv3y_ty(LL), 1024, V, 4, DEPTH> K;
+    typedef Inv3Y<float, LL, inv3y_tx(LL), inv3y_ty(LL), 1024, V, 4, DEPTH, 1, inv3y_zlds(LL, DEPTH)> K;
     FusedTapsD unused;
     unused.Lp = LL;
     return launch_fused3<K>(a, unused, taps_dev, s);
 }
 
 // depth 2 (two register sets of band loads, staggered refill) is the default where it fits the 128 registers of a 1024-thread
-// workgroup without spills (tap lengths 2, 8 and 10; 4, 6 and 12 spill a few registers, and a spill reload in the plane loop waits
-// vmcnt(0), i.e. for every load in flight); depth 1 serves the others, unaligned volumes and A/B runs
+// workgroup without spills: tap lengths 2, 8 and 10 as they are; 12 with 6 of the pending z sums in LDS
+// (inv3y_zlds; 4 and 6 taps fit that way too and run slower than depth 1; a spill reload in the plane loop would wait vmcnt(0), i.e. for every load in flight); depth 1 serves the longer
+// filters, unaligned volumes and A/B runs
 #define NDWT_INVY_CASE(LL, D2OK) \
     case LL:                     \
         if constexpr (D2OK) {    \
@@ -27,7 +28,7 @@ int launch_inv3y_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, c
         NDWT_INVY_CASE(4, false)
         NDWT_INVY_CASE(6, false)
         NDWT_INVY_CASE(10, true)
-        NDWT_INVY_CASE(12, false)
+        NDWT_INVY_CASE(12, true)
         NDWT_INVY_CASE(14, false)
         NDWT_INVY_CASE(16, false)
         NDWT_INVY_CASE(18, false)     // 64 x 24 tile: 41 haloed rows on 14 waves

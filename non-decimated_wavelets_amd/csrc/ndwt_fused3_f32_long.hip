@@ -7,8 +7,8 @@ int launch_long3_f32(bool inverse, const Fused3Args<float>& a, const FusedTapsD&
     if (!inverse) {
         if (variant != 1) {       // default: tall 64x32 tile, 1024 threads (db7 analysis 1.45 -> 1.15 ms per launch; 16 taps spill 8 registers, -5 %)
             switch (t.Lp) {
-                NDWT_FUSED_CASE(Fwd3, false, float, 14, 2)
-                NDWT_FUSED_CASE(Fwd3, false, float, 16, 2)
+                NDWT_FUSED_CASE(Fwd3, false, float, 14, 6)   // (y items of 2 rows: ndwt_fused_tile.h)
+                NDWT_FUSED_CASE(Fwd3, false, float, 16, 6)
                 default: break;
             }
         }

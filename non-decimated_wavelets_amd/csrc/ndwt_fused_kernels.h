@@ -181,15 +181,16 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
             default: return -1;                                           \
         }                                                                 \
     }                                                                     \
-    if (variant == 2) { switch (t.Lp) { NDWT_FUSED_CASE(Fwd3, false, T, 2, 2) NDWT_FUSED_CASE(Fwd3, false, T, 4, 2) NDWT_FUSED_CASE(Fwd3, false, T, 6, 2) NDWT_FUSED_CASE(Fwd3, false, T, 8, 2) } }  \
+    if (variant == 2) { switch (t.Lp) { NDWT_FUSED_CASE(Fwd3, false, T, 12, 2) NDWT_FUSED_CASE(Fwd3, false, T, 2, 2) NDWT_FUSED_CASE(Fwd3, false, T, 4, 2) NDWT_FUSED_CASE(Fwd3, false, T, 6, 2) NDWT_FUSED_CASE(Fwd3, false, T, 8, 2) } }  \
     if (variant == 1) { switch (t.Lp) { NDWT_FUSED_CASE(Fwd3, false, T, 10, 1) NDWT_FUSED_CASE(Fwd3, false, T, 12, 1) } }  \
+    if (variant == 6) { switch (t.Lp) { NDWT_FUSED_CASE(Fwd3, false, T, 8, 6) NDWT_FUSED_CASE(Fwd3, false, T, 10, 6) } }  \
     switch (t.Lp) {                                                       \
         NDWT_FUSED_CASE(Fwd3, false, T, 2, 0)                             \
         NDWT_FUSED_CASE(Fwd3, false, T, 4, 0)                             \
         NDWT_FUSED_CASE(Fwd3, false, T, 6, 0)                             \
         NDWT_FUSED_CASE(Fwd3, false, T, 8, 0)                             \
         NDWT_FUSED_CASE(Fwd3, false, T, 10, 2)   /* 10 .. 16 taps: the tall tile (db6 analysis 1.33 -> 1.02 ms per launch) */ \
-        NDWT_FUSED_CASE(Fwd3, false, T, 12, 2)                            \
+        NDWT_FUSED_CASE(Fwd3, false, T, 12, 6)   /* 12 .. 16 taps: y items of 2 rows (10 of the 16 waves in the y stage instead of 5: db6 -6 %) */ \
         default: return -1;                                               \
     }
 

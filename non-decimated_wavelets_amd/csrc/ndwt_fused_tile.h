@@ -11,6 +11,7 @@ template <> struct Fused3Tile<float, false, 0> { static constexpr int TX = 64, T
 template <> struct Fused3Tile<float, false, 1> { static constexpr int TX = 64, TY = 16, NT = 512, RY = 4, WPE = 2; };   // one column per thread: 18 / 20 taps, complex data with 10 / 12 taps
 template <> struct Fused3Tile<float, false, 2> { static constexpr int TX = 64, TY = 32, NT = 1024, RY = 4, WPE = 4; };  // tall tile, one workgroup per CU: the default for 6 .. 16 taps on volumes with >= 32 such tiles
 template <> struct Fused3Tile<float, false, 3> { static constexpr int TX = 64, TY = 16, NT = 256, RY = 4, WPE = 3; };
+template <> struct Fused3Tile<float, false, 6> { static constexpr int TX = 64, TY = 32, NT = 1024, RY = 2, WPE = 4; };  // tall tile, y items of 2 rows (twice the waves in the y stage)
 // float, synthesis
 template <> struct Fused3Tile<float, true, 0>  { static constexpr int TX = 64, TY = 16, NT = 256, RY = 2, WPE = 2; };
 template <> struct Fused3Tile<float, true, 1>  { static constexpr int TX = 64, TY = 32, NT = 1024, RY = 1, WPE = 4; };  // lane-shift kernel (Inv3S), tall tile: the float default
@@ -32,6 +33,10 @@ constexpr int kInv3YTX = 64, kInv3YTY = 32;
 // The pair-packed synthesis tile: the haloed rows (TY + L - 1) must fit the 16 waves of the workgroup at three rows per wave,
 // i.e. at most 21 lanes per haloed row.  Real data: 64 wide up to 18 taps (64x32, 18 taps 64x24), 20 taps 48x28 (22 lanes per
 // haloed 64-wide row would leave two rows per wave).  Interleaved complex (ew = 2, TX in scalars): 64 wide up to 10 taps, 12 taps 48.
+// two register sets of band loads (staggered refill) fit the 128 registers of the 1024-thread workgroup without spills for 2, 8 and
+// 10 taps as they are, and for 12 taps with 6 of the 12 pending z sums in LDS (Inv3Y::ZLDS): 512^3 db6 1.37 -> 1.30 ms per launch.
+// (4 and 6 taps fit the same way -- 2 / 4 sums in LDS -- and run SLOWER than one register set: 1.05 vs 1.02, 1.18 vs 1.08 ms.)
+constexpr int inv3y_zlds(int L, int depth, int ew = 1) { return (depth == 2 && ew == 1 && L == 12) ? 6 : 0; }
 constexpr int inv3y_ty(int L, int ew = 1) { return ew == 2 ? kInv3YTY : (L <= 16 ? kInv3YTY : (L <= 18 ? 24 : 28)); }
 constexpr int inv3y_tx(int L, int ew = 1) { return ew == 2 ? (L <= 10 ? kInv3YTX : 48) : (L <= 18 ? kInv3YTX : 48); }
 }  // namespace ndwt

@@ -82,10 +82,12 @@ int runY(ndwt::Fused3Args<T>& a, const double* lo, const double* hi) {
 
 template <typename T, int TX, int TY, int NT, bool ALL, int DEPTH, int EW = 1>
 int dispatchY(int Lp, int vec4, ndwt::Fused3Args<T>& a, const double* lo, const double* hi) {
+    // pending z sums in LDS: the production choice on the production tile, half of them on the small test tile (every tap length)
+#define ZL(LL) (ALL ? ((DEPTH == 2 && LL >= 4) ? LL / 2 : 0) : ndwt::inv3y_zlds(LL, DEPTH, EW))
 #define CASEY(LL)                                                                   \
     case LL:                                                                        \
-        return vec4 ? runY<ndwt::Inv3Y<T, LL, TX, TY, NT, true, 2, DEPTH, EW>, T>(a, lo, hi)  \
-                    : runY<ndwt::Inv3Y<T, LL, TX, TY, NT, false, 2, DEPTH, EW>, T>(a, lo, hi);
+        return vec4 ? runY<ndwt::Inv3Y<T, LL, TX, TY, NT, true, 2, DEPTH, EW, ZL(LL)>, T>(a, lo, hi)  \
+                    : runY<ndwt::Inv3Y<T, LL, TX, TY, NT, false, 2, DEPTH, EW, ZL(LL)>, T>(a, lo, hi);
     if constexpr (ALL) {
         switch (Lp) {
             CASEY(2) CASEY(4) CASEY(6) CASEY(8) CASEY(10) CASEY(12) CASEY(14) CASEY(16) CASEY(18) CASEY(20)
@@ -98,6 +100,7 @@ int dispatchY(int Lp, int vec4, ndwt::Fused3Args<T>& a, const double* lo, const 
         }
     }
 #undef CASEY
+#undef ZL
 }
 
 template <typename T, template <typename, int, int, int, int, int, bool, int, int> class KIND, int TX, int TY, int NT, int RY, bool ALL, int EW = 1>
