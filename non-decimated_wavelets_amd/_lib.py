@@ -22,7 +22,7 @@ NDWT_PATH_AUTO, NDWT_PATH_GENERIC = 0, 1
 
 EXPORTS = [
     "ndwt_wave_filters", "ndwt_num_bands", "ndwt_level_from_bands", "ndwt_plan_create", "ndwt_plan_create_slab", "ndwt_plan_destroy",
-    "ndwt_plan_set_path", "ndwt_plan_describe", "ndwt_plan_set_tuning", "ndwt_plan_set_variant", "ndwt_plan_set_profiling", "ndwt_plan_get_profile", "ndwt_dec", "ndwt_rec", "ndwt_dec_host",
+    "ndwt_plan_set_path", "ndwt_plan_describe", "ndwt_plan_set_tuning", "ndwt_plan_set_variant", "ndwt_plan_set_fused_level1", "ndwt_plan_set_profiling", "ndwt_plan_get_profile", "ndwt_dec", "ndwt_rec", "ndwt_dec_host",
     "ndwt_rec_host", "ndwt_shrink", "ndwt_denoise", "ndwt_denoise_host", "ndwt_dec_split", "ndwt_rec_split", "ndwt_dec_split_host", "ndwt_rec_split_host", "ndwt_slab_halo", "ndwt_analysis_level_slab", "ndwt_synthesis_level_slab",
     "ndwt_analysis_level_slab_split", "ndwt_synthesis_level_slab_ext", "ndwt_analysis_level_slab_part",
     "ndwt_synthesis_level_slab_part", "ndwt_analysis_level_slab_runs", "ndwt_synthesis_level_slab_runs", "ndwt_last_error",
@@ -76,6 +76,7 @@ def lib() -> ctypes.CDLL:
     L.ndwt_plan_set_path.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.ndwt_plan_set_tuning.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     L.ndwt_plan_set_variant.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5
+    L.ndwt_plan_set_fused_level1.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.ndwt_plan_set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.ndwt_plan_get_profile.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
     L.ndwt_plan_describe.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]

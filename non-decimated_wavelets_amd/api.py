@@ -74,6 +74,11 @@ class Plan:
         L.check(L.lib().ndwt_plan_set_variant(self._h, int(fwd), int(inv), int(zchunk_fwd), int(zchunk_inv), int(fp64_fused)))
         return self
 
+    def set_fused_level1(self, on: bool):
+        """tuning hook: False = denoise() keeps the level-1 detail bands in memory (the round-2 path)"""
+        L.check(L.lib().ndwt_plan_set_fused_level1(self._h, int(bool(on))))
+        return self
+
     def set_variant_from_env(self):
         """tools/ only: NDWT_VARIANT_FWD / NDWT_VARIANT_INV / NDWT_ZCHUNK_FWD / NDWT_ZCHUNK_INV / NDWT_FP64_FUSED of the caller's
         environment, applied through set_variant (the library itself never reads the environment)"""

@@ -92,6 +92,8 @@ struct ndwt_plan {
     double shrink_thr;
     void* coef;                        // coefficient scratch of ndwt_denoise (all bands of the last level used), lazily allocated
     size_t coef_bytes;
+    void* taps_den;                    // device tap table of the fused level-1 denoising kernel (TapsDen<float, L>), lazily built
+    int no_fused_level1;               // tuning hook: ndwt_denoise keeps the level-1 detail bands in memory (the round-2 path)
     // optional per-kernel timing with HIP events on the launch stream (bench.py's roofline figures)
     int profiling;
     std::vector<ProfRec>* prof;
@@ -1019,6 +1021,7 @@ int ndwt_plan_destroy(ndwt_plan* p) {
         if (p->approx_base[i]) (void)hipFree(p->approx_base[i]);
     if (p->tmp) (void)hipFree(p->tmp);
     if (p->coef) (void)hipFree(p->coef);
+    if (p->taps_den) (void)hipFree(p->taps_den);
     for (int i = 0; i < 2; ++i)
         if (p->taps_dev[i]) (void)hipFree(p->taps_dev[i]);
     if (p->prof) {
@@ -1084,6 +1087,14 @@ int ndwt_plan_set_variant(ndwt_plan* p, int variant_fwd, int variant_inv, int zc
     if (zchunk_fwd >= 0) p->zchunk_dir[0] = zchunk_fwd;
     if (zchunk_inv >= 0) p->zchunk_dir[1] = zchunk_inv;
     if (fp64_fused >= 0) p->fp64_fused = fp64_fused ? 1 : 0;
+    return NDWT_OK;
+}
+
+// test / tuning hook: 0 = ndwt_denoise materialises the level-1 detail bands (dec, thresholding in the synthesis loads, rec);
+// 1 (default) = the fused level-1 kernel wherever it applies
+int ndwt_plan_set_fused_level1(ndwt_plan* p, int enable) {
+    if (!p) return fail(NDWT_ERR_INVALID_ARG, "null plan");
+    p->no_fused_level1 = enable ? 0 : 1;
     return NDWT_OK;
 }
 
@@ -1201,25 +1212,133 @@ int ndwt_shrink(ndwt_plan* p, void* y, int level, double threshold, int mode, vo
     return ndwt_shrink_pitched(p, y, 0, level, threshold, mode, stream);
 }
 
+// ---- level 1 of a denoising step without its detail bands in memory (Den3, ndwt_device.h) ----
+// Float, real, 3-D, reference dilation, the same tap length L <= 8 on every axis, rows of whole 16-byte groups.
+static bool den3_eligible(const ndwt_plan* p, int* Lp_out) {
+    if (p->no_fused_level1 || p->dtype != NDWT_F32 || p->complexity != NDWT_REAL || p->ndim != 3 || p->dilation != NDWT_DILATION_REFERENCE)
+        return false;
+    int Lp = 0;
+    if (!fused3_eligible(p, 1, &Lp) || Lp > 8 || !inv3y_plan_ok(p, Lp)) return false;
+    for (int ax = 0; ax < 3; ++ax)
+        if (p->filt[ax].len != Lp) return false;
+    if (p->dims[0] % 4 != 0) return false;
+    *Lp_out = Lp;
+    return true;
+}
+
+static int den3_taps(ndwt_plan* p, int Lp) {
+    if (p->taps_den) return NDWT_OK;
+    const FusedTapsD ts = fused_taps(p, Lp, true), ta = fused_taps(p, Lp, false);
+    std::vector<float> h;                                 // TapsDen<float, Lp>: Taps3Y (lo[3][L], hi[3][L], xplo[L+1][2], xphi[L+1][2]), alo[3][L], azp[L][2]
+    for (int ax = 0; ax < 3; ++ax) for (int j = 0; j < Lp; ++j) h.push_back((float)ts.lo[ax][j]);
+    for (int ax = 0; ax < 3; ++ax) for (int j = 0; j < Lp; ++j) h.push_back((float)ts.hi[ax][j]);
+    for (int hi = 0; hi < 2; ++hi)
+        for (int k = 0; k <= Lp; ++k)
+            for (int hh = 0; hh < 2; ++hh) {
+                const int j = k - hh;
+                h.push_back((j >= 0 && j < Lp) ? (float)(hi ? ts.hi[0][j] : ts.lo[0][j]) : 0.0f);
+            }
+    for (int ax = 0; ax < 3; ++ax) for (int j = 0; j < Lp; ++j) h.push_back((float)ta.lo[ax][j]);
+    for (int j = 0; j < Lp; ++j) { h.push_back((float)ta.lo[2][j]); h.push_back((float)ta.hi[2][j]); }
+    // the kernel derives the analysis high-pass taps of x and y from the low-pass ones: ahi[j] = (-1)^j alo[L-1-j]
+    for (int ax = 0; ax < 2; ++ax)
+        for (int j = 0; j < Lp; ++j)
+            if ((float)ta.hi[ax][j] != ((j % 2) ? -1.0f : 1.0f) * (float)ta.lo[ax][Lp - 1 - j])
+                return fail(NDWT_ERR_UNSUPPORTED, "internal: analysis taps are not a mirrored pair");
+    hipError_t e = hipMalloc(&p->taps_den, h.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(p->taps_den, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (p->taps_den) { (void)hipFree(p->taps_den); p->taps_den = nullptr; }
+        return fail(NDWT_ERR_ALLOC, "uploading the tap table of the fused level-1 kernel failed: %s", hipGetErrorString(e));
+    }
+    return NDWT_OK;
+}
+
+// kind 0: approximation band of one analysis level (x -> out);  kind 1: Den3 (x, approximation -> out)
+static int den3_launch(ndwt_plan* p, int kind, int Lp, const float* x, const float* apx, float* out, hipStream_t s) {
+    Fused3Args<float> a;
+    memset(&a, 0, sizeof a);
+    a.n1 = (int)p->dims[0]; a.n2 = (int)p->dims[1]; a.n3 = (int)p->dims[2];
+    a.nbatch = 1;
+    a.z_wrap = 1;
+    a.in[0] = x; a.in[1] = apx;
+    a.out[0] = out;
+    a.in_bstride = a.out_bstride = p->vol;
+    if (kind == 1) {
+        a.shrink_thr = (float)p->shrink_thr;
+        a.shrink_mask = 0xFE;
+        a.shrink_hard = p->shrink_mode == 2;
+    }
+    // one workgroup per CU (1024 threads); Den3's march starts 2 (L - 1) planes before its first output plane
+    fused3_geometry(a, 64, 32, kind == 1 ? 2 * Lp - 1 : Lp, p->target_blocks > 0 ? p->target_blocks : p->num_cus, p->force_zchunk);
+    float* outs[1] = {out};
+    a.nt = nt_store_ok<float>(a.rs, a.plane, p->vol, outs, 1);
+    prof_begin(p, kind == 1 ? NDWT_KERNEL_FUSED_SYNTHESIS : NDWT_KERNEL_FUSED_ANALYSIS, s);
+    const bool vec4 = aligned_vec4<float>(x) && aligned_vec4<float>(out);
+    int rc = kind == 1 ? launch_den3_f32(a, Lp, p->taps_den, s) : launch_fwd3_low_f32(a, Lp, vec4, p->taps_dev[0], s);
+    prof_end(p, s, rc);
+    if (rc == -1) return fail(NDWT_ERR_UNSUPPORTED, "fused level-1 kernel not instantiated for tap length %d", Lp);
+    if (rc == -2) return fail(NDWT_ERR_UNSUPPORTED, "internal: launch geometry does not match the 64 x 32 tile");
+    if (rc != 0) return fail(NDWT_ERR_HIP, "fused level-1 kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return NDWT_OK;
+}
+
+static int ensure_coef(ndwt_plan* p, size_t need) {
+    if (need <= p->coef_bytes) return NDWT_OK;
+    if (p->coef) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(p->coef));
+        p->coef = nullptr;
+        p->coef_bytes = 0;
+    }
+    hipError_t e = hipMalloc(&p->coef, need);
+    if (e != hipSuccess) return fail(NDWT_ERR_ALLOC, "hipMalloc(%zu bytes) for the coefficient scratch failed: %s", need, hipGetErrorString(e));
+    p->coef_bytes = need;
+    return NDWT_OK;
+}
+
+// dec -> shrink -> rec with level 1 fused: x -> approximation of level 1 (band 0 only) -> levels 2 .. `level` as a (level - 1)-level
+// transform of that band (the reference applies the same filters at every level, nd_dwt_3D.m:178-186) with the thresholding in the
+// synthesis kernels' loads -> Den3(x, reconstructed approximation).  Volumes moved at level 1: 5 instead of 18.
+static int denoise_fused_level1(ndwt_plan* p, int Lp, const float* x, float* out, int level, double threshold, int mode, hipStream_t s) {
+    int rc = den3_taps(p, Lp);
+    if (rc) return rc;
+    rc = ensure_tmp(p, (size_t)p->vol * sizeof(float) + kApproxSkew);
+    if (rc) return rc;
+    float* a1 = (float*)((char*)p->tmp + kApproxSkew);   // level-1 approximation, then its reconstruction (256 B off the alignment, like the ping-pong scratch)
+    p->shrink_mode = mode == NDWT_SHRINK_HARD ? 2 : 1;
+    p->shrink_thr = threshold;
+    rc = den3_launch(p, 0, Lp, x, nullptr, a1, s);
+    if (rc == NDWT_OK && level > 1) {
+        const int64_t pitch = ndwt_band_pitch(p);
+        rc = ensure_coef(p, (size_t)pitch * p->esize * (size_t)ndwt_num_bands(3, level - 1));
+        if (rc == NDWT_OK) rc = dec_impl<float>(p, a1, (float*)p->coef, pitch, level - 1, s);
+        if (rc == NDWT_OK) rc = rec_impl<float>(p, (const float*)p->coef, pitch, a1, level - 1, s);   // (thresholding in the band loads)
+    }
+    if (rc == NDWT_OK) rc = den3_launch(p, 1, Lp, x, a1, out, s);
+    p->shrink_mode = 0;
+    return rc;
+}
+
 int ndwt_denoise(ndwt_plan* p, const void* x, void* out, int level, double threshold, int mode, void* stream) {
     int rc = shrink_check(p, level, threshold, mode);
     if (rc) return rc;
     if (!x || !out) return fail(NDWT_ERR_INVALID_ARG, "null data pointer");
     HIP_TRY(hipSetDevice(p->device));
+    {
+        // the finest level without its detail bands in memory, where the fused level-1 kernel applies (it reads x around every
+        // output voxel while other workgroups write `out`: not in place)
+        int Lp1 = 0;
+        const char *xb = (const char*)x, *ob = (const char*)out;
+        const size_t nbytes = (size_t)p->vol * p->esize;
+        const bool disjoint = xb + nbytes <= ob || ob + nbytes <= xb;
+        if (den3_eligible(p, &Lp1) && disjoint && aligned_vec4<float>(x) && aligned_vec4<float>(out))
+            return denoise_fused_level1(p, Lp1, (const float*)x, (float*)out, level, threshold, mode, (hipStream_t)stream);
+    }
     // the scratch coefficients are pitched (ndwt_band_pitch): nobody else reads them
     const int64_t pitch = ndwt_band_pitch(p);
-    const size_t need = (size_t)pitch * p->comp * p->esize * (size_t)ndwt_num_bands(p->ndim, level);
-    if (need > p->coef_bytes) {
-        if (p->coef) {
-            HIP_TRY(hipDeviceSynchronize());
-            HIP_TRY(hipFree(p->coef));
-            p->coef = nullptr;
-            p->coef_bytes = 0;
-        }
-        hipError_t e = hipMalloc(&p->coef, need);
-        if (e != hipSuccess) return fail(NDWT_ERR_ALLOC, "hipMalloc(%zu bytes) for the coefficient scratch failed: %s", need, hipGetErrorString(e));
-        p->coef_bytes = need;
-    }
+    rc = ensure_coef(p, (size_t)pitch * p->comp * p->esize * (size_t)ndwt_num_bands(p->ndim, level));
+    if (rc) return rc;
     rc = ndwt_dec_pitched(p, x, p->coef, pitch, level, stream);
     if (rc) return rc;
     if (fused_shrink_capable(p)) {
@@ -1242,14 +1361,18 @@ int ndwt_denoise_host(ndwt_plan* p, const void* x, void* out, int level, double 
     if (!x || !out) return fail(NDWT_ERR_INVALID_ARG, "null data pointer");
     HIP_TRY(hipSetDevice(p->device));
     const size_t bx = (size_t)p->vol * p->esize;
-    void* dx = nullptr;
-    if (hipMalloc(&dx, bx) != hipSuccess) return fail(NDWT_ERR_ALLOC, "hipMalloc of the staging buffer (%zu bytes) failed", bx);
+    void *dx = nullptr, *dout = nullptr;
+    if (hipMalloc(&dx, bx) != hipSuccess || hipMalloc(&dout, bx) != hipSuccess) {
+        if (dx) (void)hipFree(dx);
+        return fail(NDWT_ERR_ALLOC, "hipMalloc of the staging buffers (2 x %zu bytes) failed", bx);
+    }
     hipError_t e = hipMemcpy(dx, x, bx, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        rc = ndwt_denoise(p, dx, dx, level, threshold, mode, nullptr);     // in place on the staging buffer (dec reads x before rec writes it)
-        if (rc == NDWT_OK) e = hipMemcpy(out, dx, bx, hipMemcpyDeviceToHost);
+        rc = ndwt_denoise(p, dx, dout, level, threshold, mode, nullptr);
+        if (rc == NDWT_OK) e = hipMemcpy(out, dout, bx, hipMemcpyDeviceToHost);
     }
     (void)hipFree(dx);
+    (void)hipFree(dout);
     if (rc) return rc;
     if (e != hipSuccess) return fail(NDWT_ERR_HIP, "staging copy failed: %s", hipGetErrorString(e));
     return NDWT_OK;

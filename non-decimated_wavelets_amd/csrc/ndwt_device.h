@@ -305,8 +305,11 @@ template <int RSB> struct RowPair {
 // ---------------------------------------------------------------------------------- analysis ----
 // EW = scalars per element along x: 1 real, 2 interleaved complex (n1 then counts scalars and the x taps step over
 // (re, im) pairs; the y and z stages are component-wise and do not change)
-template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, int WPE_ = 2, int EW_ = 1> struct Fwd3 {
+// LOWONLY_: only band 0 (the approximation) is computed through and stored -- the analysis that feeds the deeper levels of a
+// denoising step whose finest level never materialises its detail bands (Den3)
+template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, int WPE_ = 2, int EW_ = 1, bool LOWONLY_ = false> struct Fwd3 {
     static constexpr int L = L_, TX = TX_, TY = TY_, NT = NT_, RY = RY_, EW = EW_;
+    static constexpr bool LOWONLY = LOWONLY_;
     static constexpr bool VEC4 = VEC4_;
     static constexpr int NE = VEC4 ? 1 : 4;              // offsets kept per column
     static constexpr int WPE = WPE_;                     // waves per SIMD the register budget is sized for
@@ -442,7 +445,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
                                 NDWT_SFOR(sub, CH)
                                     const v2 z = LD::get(zin[t], sub);
                                     l[i][sub] += tp.lo[1][j] * z;
-                                    h[i][sub] += tp.hi[1][j] * z;
+                                    if constexpr (!LOWONLY) h[i][sub] += tp.hi[1][j] * z;
                                 NDWT_SEND
                             }
                         NDWT_SEND
@@ -457,7 +460,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
                     LD::set(hi, sub, h[i][sub]);
                 NDWT_SEND
                 sh.ys[yg * RY + i][0][pc] = lo;
-                sh.ys[yg * RY + i][1][pc] = hi;
+                if constexpr (!LOWONLY) sh.ys[yg * RY + i][1][pc] = hi;
             NDWT_SEND
         }
     }
@@ -474,6 +477,9 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
             int q = (it / (TX / 4)) % 2;
             int y = it / ((TX / 4) * 2);
             int gy = tc.y0 + y, gx = tc.x0 + 4 * xg;
+            if constexpr (LOWONLY) {
+                if (q != 0) continue;                     // the y-high plane feeds detail bands only
+            }
             v2 v[XV];
             lds_load_run<T, XV>(sh.ys[y][q], 4 * xg, v);
             if (gy >= a.n2 || gx >= a.n1) continue;
@@ -484,11 +490,22 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
                 NDWT_UNROLL
                 for (int j = 0; j < L; ++j) {
                     lo += tp.lo[0][j] * v[4 * GL + e + (j - LH) * EW];
-                    hi += tp.hi[0][j] * v[4 * GL + e + (j - LH) * EW];
+                    if constexpr (!LOWONLY) hi += tp.hi[0][j] * v[4 * GL + e + (j - LH) * EW];
                 }
                 o00[e] = lo.x; o01[e] = lo.y; o10[e] = hi.x; o11[e] = hi.y;
             }
             long long off = obase + (long long)z * a.plane + (long long)gy * a.rs + gx;
+            if constexpr (LOWONLY) {
+                T* b0 = a.out[0] + off;
+                if constexpr (VEC4) {
+                    stream_store(reinterpret_cast<v4*>(b0), o00, a.nt);
+                } else {
+                    NDWT_UNROLL
+                    for (int e = 0; e < 4; ++e)
+                        if (gx + e < a.n1) b0[e] = o00[e];
+                }
+                continue;
+            }
             T* b00 = a.out[2 * q] + off;
             T* b10 = a.out[2 * q + 1] + off;
             T* b01 = a.out[2 * q + 4] + off;
@@ -1103,7 +1120,9 @@ template <typename T, int L> struct Taps3Y {             // the first two member
 // ZLDS_ > 0: that many of the L pending z sums of a thread live in LDS instead of registers (each is read, updated and written
 // back once per plane by its own thread: no barrier) -- what lets 12 taps keep two register sets of band loads inside the 128
 // registers of a 1024-thread workgroup without spills.
-template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 4, int DEPTH_ = 1, int EW_ = 1, int ZLDS_ = 0> struct Inv3Y {
+// XH_ > 0: every haloed row carries that many more lanes on each side than the synthesis needs (Den3: the lanes whose coefficients
+// exist only as inputs of the neighbouring lanes' x analysis).
+template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 4, int DEPTH_ = 1, int EW_ = 1, int ZLDS_ = 0, int XH_ = 0> struct Inv3Y {
     static_assert(sizeof(T) == 4, "pair-packed synthesis: float only (v_pk_fma_f32)");
     static_assert(EW_ == 1 || EW_ == 2, "real or interleaved complex data");
     static constexpr int L = L_, TX = TX_, TY = TY_, NT = NT_, WPE = WPE_, EW = EW_;
@@ -1115,7 +1134,8 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
     static constexpr int NE = VEC4 ? 1 : 4;
     static constexpr int LH = L / 2, RH = L / 2 - 1;
     static constexpr int GL = (LH * EW + 3) / 4, GR = (RH * EW + 3) / 4;
-    static constexpr int NG = TX / 4 + GL + GR;          // lanes per haloed row
+    static constexpr int XH = XH_;
+    static constexpr int NG = TX / 4 + GL + GR + 2 * XH; // lanes per haloed row
     static constexpr int NR = TY + L - 1;                // haloed rows: loaded, x-synthesised, kept in LDS
     static constexpr int RPW = 64 / NG;                  // rows per wave
     static constexpr int NW = NT / 64;
@@ -1274,7 +1294,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
             bool valid;
             lane_item(tid, k, ug, r, valid);
             const int y = modn(tc.y0 - LH + r, a.n2);
-            const int xb = tc.x0 - 4 * GL + 4 * ug;
+            const int xb = tc.x0 - 4 * (GL + XH) + 4 * ug;
             NDWT_SFOR(e, NE)
                 st.off[k][e] = valid ? (unsigned)(y * a.rs + modn(xb + e, a.n1)) * (unsigned)sizeof(T) : kNoRow;
             NDWT_SEND
@@ -1378,12 +1398,12 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
                         NDWT_SCHED_FENCE();               // hipcc otherwise hoists every DPP move of a y-bit ahead of the FMAs
                     NDWT_SEND
                 NDWT_SEND
-                if (valid && ug >= GL && ug < GL + TX / 4) {
+                if (valid && ug >= GL + XH && ug < GL + XH + TX / 4) {
                     const chunk c0 = {acc[0][0].x, acc[0][0].y, acc[1][0].x, acc[1][0].y};
                     const chunk c1 = {acc[0][1].x, acc[0][1].y, acc[1][1].x, acc[1][1].y};
                     chunk* row = sh.xs[buf][yb][r];
-                    row[LD::S(2 * (ug - GL))] = c0;
-                    row[LD::S(2 * (ug - GL) + 1)] = c1;
+                    row[LD::S(2 * (ug - GL - XH))] = c0;
+                    row[LD::S(2 * (ug - GL - XH) + 1)] = c1;
                 }
             NDWT_SEND
         NDWT_SEND
@@ -1550,6 +1570,237 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
             for (int p = 0; p < nplanes; p += 2) {
                 iter(std::integral_constant<int, 0>{}, p);
                 if (p + 1 < nplanes) iter(std::integral_constant<int, 1>{}, p + 1);
+            }
+        }
+    }
+};
+
+// ------------------------------------------------ level 1 of dec -> shrink -> rec in ONE launch ----
+// The consumer of SURVEY 8f-3 (reference README.md:2, "iterative algorithm"): the finest level of a denoising step without its
+// seven detail bands ever existing in memory.  The kernel reads the signal x and the reconstructed level-1 approximation,
+// RECOMPUTES the level-1 detail coefficients of its haloed tile from x (the analysis of Fwd3: z in a rotating register
+// window, y from an LDS tile, x with the neighbouring lanes' values by DPP wave shifts), thresholds them in registers, and
+// hands all eight bands to the synthesis stages of Inv3Y -- whose lanes hold exactly these values: 4 x of one haloed row.
+// Level 1 then moves x (read twice: once here, once by the approximation-only analysis that feeds the deeper levels), the
+// approximation (written and read once each) and the output: 5 volumes instead of 18.  Arithmetic is 2.3x the synthesis
+// kernel's (the analysis runs on a tile haloed by L - 1 more samples per axis), which the removed loads pay for: the
+// synthesis kernel is bound by its 8 band loads per lane and plane, this one issues 2.
+//   per coefficient plane p:  A: z analysis of raw plane -> zs (LDS)  | barrier |  B: y analysis (zs) + x analysis (DPP) +
+//   shrink + x synthesis (DPP) -> xs[p & 1]  | barrier |  C: y / z synthesis (Inv3Y::ysyn / zsyn), then A of plane p + 1
+// Float, real data, tap stride 1, every axis with the same tap length L <= 8 (one extra lane per side of a haloed row).
+template <typename T, int L> struct TapsDen {
+    Taps3Y<T, L> syn;        // synthesis taps, the table of Inv3Y
+    T alo[3][L];             // analysis low-pass taps (x, y, z); the high-pass ones are derived: ahi[j] = (-1)^j alo[L-1-j]
+    T azp[L][2];             // (alo_z[j], ahi_z[j]): the z stage produces (lo, hi) pairs from one broadcast sample
+};
+
+template <typename T, int L_, int NT_ = 1024, int WPE_ = 4> struct Den3 {
+    static_assert(sizeof(T) == 4, "float only");
+    static constexpr int L = L_, TX = 64, TY = 32, NT = NT_, WPE = WPE_;
+    static constexpr int ALH = L / 2 - 1, ARH = L / 2;   // analysis: samples left / right of the output index
+    static constexpr int XH = (ARH + 3) / 4;             // extra lanes per side of a haloed row
+    typedef Inv3Y<T, L, TX, TY, NT, true, WPE, 1, 1, 0, XH> Y;
+    static constexpr int NG = Y::NG, RPW = Y::RPW, NW = NT / 64;
+    static constexpr int NRS = Y::NR;                    // rows of coefficients under the tile (TY + L - 1)
+    static constexpr int NRA = NRS + L - 1;              // rows of raw samples under those
+    static constexpr int WCA = 2 * NG;                   // chunks per row of the z-analysed tile
+    static_assert(XH == 1 && Y::NRND == 1 && RPW * NW >= NRA, "tile shape: one round of rows, x neighbours one lane away");
+    typedef typename VecT<T>::v2 v2;
+    typedef typename VecT<T>::v4 v4;
+    typedef Lds<T> LD;
+    typedef v4 chunk;
+    typedef TapsDen<T, L> Taps;
+    typedef Fused3Args<T> Args;                          // in[0] = x, in[1] = approximation band, out[0]; shrink_thr / shrink_hard
+
+    struct Shared : Y::Shared {
+        chunk zs[NRA][WCA];        // (lo_z, hi_z) pairs of the raw tile: [row][x pair-of-pairs], swizzled like every LDS row here
+    };
+    struct State : Y::State {
+        v4 win[L];                 // raw planes of this lane's z-stage row (4 x), rotating
+        v4 nxt;                    // prefetched raw plane
+        v4 apx;                    // prefetched approximation values of this lane's coefficient row
+        v2 ya[2][4];               // y-analysed (z-bit 0, z-bit 1) pairs of this lane's 4 x: [y-bit][x]; the neighbouring lanes read them
+        unsigned aoff;             // byte offset of the z-stage row inside a plane (kNoRow: this lane holds none)
+    };
+    struct RegTapsA {
+        v2 ax[L / 2], ay[L / 2];   // (alo[2m], alo[2m+1]) of the x and y axes
+        v2 az[L];                  // (alo_z[j], ahi_z[j])
+    };
+    static NDWT_DEV void load_taps_a(RegTapsA& ta, const Taps& tp) {
+        NDWT_SFOR(m, L / 2)
+            ta.ax[m] = Y::pinned(v2{tp.alo[0][2 * m], tp.alo[0][2 * m + 1]});
+            ta.ay[m] = Y::pinned(v2{tp.alo[1][2 * m], tp.alo[1][2 * m + 1]});
+        NDWT_SEND
+        NDWT_SFOR(j, L)
+            ta.az[j] = Y::pinned(v2{tp.azp[j][0], tp.azp[j][1]});
+        NDWT_SEND
+    }
+    // acc += x * analysis low-pass tap J (HIGH = false) or high-pass tap J = (-1)^J low-pass tap L-1-J
+    template <int J, bool HIGH> static NDWT_DEV void tap_a(v2& acc, const v2 x, const v2 (&lo)[L / 2]) {
+        constexpr int jj = HIGH ? L - 1 - J : J;
+        Y::template pk_fma_s<jj & 1, HIGH && (J % 2 == 1)>(acc, x, lo[jj / 2]);
+    }
+
+    // z-stage rows: NRA of them, RPW per wave, the lane layout of Inv3Y (lane = (row of the wave, group of 4 x))
+    static NDWT_DEV void lane_item_a(int tid, int& ug, int& r, bool& valid) {
+        const int lane = tid % 64, wv = tid / 64;
+        const int rs = lane / NG;
+        ug = lane % NG;
+        r = wv * RPW + rs;
+        valid = rs < RPW && r < NRA;
+        if (r >= NRA) r = NRA - 1;
+    }
+    static NDWT_DEV void setup_a(State& st, const Args& a, const TileCoord& tc, int tid) {
+        int ug, r;
+        bool valid;
+        lane_item_a(tid, ug, r, valid);
+        const int y = modn(tc.y0 - Y::LH - ALH + r, a.n2);
+        const int xb = tc.x0 - 4 * (Y::GL + XH) + 4 * ug;
+        st.aoff = valid ? (unsigned)(y * a.rs + modn(xb, a.n1)) * (unsigned)sizeof(T) : Y::kNoRow;
+        st.nxt = (v4)(T(0));
+        st.apx = (v4)(T(0));
+        NDWT_SFOR(j, L)
+            st.win[j] = (v4)(T(0));
+        NDWT_SEND
+    }
+    static NDWT_DEV void load_x(State& st, const Args& a, int zraw) {
+        const long long zm = (long long)modn(zraw, a.n3);
+        if (st.aoff != Y::kNoRow) st.nxt = Y::template gload<v4>(a.in[0] + zm * a.plane, st.aoff);
+    }
+    static NDWT_DEV void load_apx(State& st, const Args& a, int zc) {
+        const long long zm = (long long)modn(zc, a.n3);
+        if (st.off[0][0] != Y::kNoRow) st.apx = Y::template gload<v4>(a.in[1] + zm * a.plane, st.off[0][0]);
+    }
+
+    // z analysis of the newest raw plane: rotation R puts it into slot (R+L-1)%L, tap j reads slot (R+j)%L (Fwd3::zstage)
+    template <int R> static NDWT_DEV void zana(State& st, Shared& sh, const RegTapsA& ta, int tid) {
+        st.win[(R + L - 1) % L] = st.nxt;
+        v2 acc[4];
+        acc[0] = acc[1] = acc[2] = acc[3] = (v2)(T(0));
+        NDWT_SFOR(j, L)
+            const v4 w = st.win[(R + j) % L];
+            const v2 w01 = {w[0], w[1]}, w23 = {w[2], w[3]};
+            Y::template pk_fma_bt<0, false, false, false>(acc[0], w01, ta.az[j]);    // (lo, hi) += w0 * (alo_z[j], ahi_z[j])
+            Y::template pk_fma_bt<1, false, false, false>(acc[1], w01, ta.az[j]);
+            Y::template pk_fma_bt<0, false, false, false>(acc[2], w23, ta.az[j]);
+            Y::template pk_fma_bt<1, false, false, false>(acc[3], w23, ta.az[j]);
+        NDWT_SEND
+        int ug, r;
+        bool valid;
+        lane_item_a(tid, ug, r, valid);
+        if (valid) lds_store_run<T, 4>(sh.zs[r], 4 * ug, acc);
+    }
+    template <int R> static NDWT_DEV void zdispatch_a(int r, State& st, Shared& sh, const RegTapsA& ta, int tid) {
+        if constexpr (R < L) {
+            if (r == R) zana<R>(st, sh, ta, tid);
+            else zdispatch_a<R + 1>(r, st, sh, ta, tid);
+        }
+    }
+
+    // y analysis of this lane's 4 x of coefficient row r: rows r .. r+L-1 of the z-analysed tile
+    static NDWT_DEV void yana(State& st, Shared& sh, const RegTapsA& ta, int tid) {
+        int ug, r;
+        bool valid;
+        Y::lane_item(tid, 0, ug, r, valid);               // (r is clamped to a row of the tile: every lane reads inside zs)
+        v2 lo[4], hi[4];
+        NDWT_SFOR(e, 4)
+            lo[e] = (v2)(T(0));
+            hi[e] = (v2)(T(0));
+        NDWT_SEND
+        const int p0 = LD::S(2 * ug), p1 = LD::S(2 * ug + 1);
+        NDWT_SFOR(j, L)
+            const chunk c0 = sh.zs[r + j][p0], c1 = sh.zs[r + j][p1];
+            const v2 z0 = {c0[0], c0[1]}, z1 = {c0[2], c0[3]}, z2 = {c1[0], c1[1]}, z3 = {c1[2], c1[3]};
+            tap_a<j, false>(lo[0], z0, ta.ay); tap_a<j, true>(hi[0], z0, ta.ay);
+            tap_a<j, false>(lo[1], z1, ta.ay); tap_a<j, true>(hi[1], z1, ta.ay);
+            tap_a<j, false>(lo[2], z2, ta.ay); tap_a<j, true>(hi[2], z2, ta.ay);
+            tap_a<j, false>(lo[3], z3, ta.ay); tap_a<j, true>(hi[3], z3, ta.ay);
+        NDWT_SEND
+        NDWT_SFOR(e, 4)
+            st.ya[0][e] = lo[e];
+            st.ya[1][e] = hi[e];
+        NDWT_SEND
+    }
+
+    // x analysis: the window of this lane's 4 outputs reaches ALH samples into the lane before and ARH into the lane after;
+    // the results are the eight bands of the lane's 4 x, in the registers the synthesis x stage reads (band = x-bit + 2 y-bit + 4 z-bit)
+    template <class Exec> static NDWT_DEV void xana(Exec& ex, State& st, const RegTapsA& ta, int tid) {
+        NDWT_SFOR(yb, 2)
+            v2 lo[4], hi[4];
+            NDWT_SFOR(e, 4)
+                lo[e] = (v2)(T(0));
+                hi[e] = (v2)(T(0));
+            NDWT_SEND
+            NDWT_SFOR(ii, 4 + L - 1)
+                constexpr int i = ii - ALH;                // x offset of the window entry from the lane's first x
+                constexpr int D = i < 0 ? -1 : (i >= 4 ? 1 : 0);
+                constexpr int c = (i + 4) % 4;
+                const v2 w = {NDWT_LANE_SHIFT(ex, tid, D, s.ya[yb][c].x), NDWT_LANE_SHIFT(ex, tid, D, s.ya[yb][c].y)};
+                NDWT_SFOR(e, 4)
+                    constexpr int j = i - e + ALH;
+                    if constexpr (j >= 0 && j < L) {
+                        tap_a<j, false>(lo[e], w, ta.ax);
+                        tap_a<j, true>(hi[e], w, ta.ax);
+                    }
+                NDWT_SEND
+            NDWT_SEND
+            st.raw[0][0][0 + 2 * yb] = v4{lo[0].x, lo[1].x, lo[2].x, lo[3].x};
+            st.raw[0][0][1 + 2 * yb] = v4{hi[0].x, hi[1].x, hi[2].x, hi[3].x};
+            st.raw[0][0][4 + 2 * yb] = v4{lo[0].y, lo[1].y, lo[2].y, lo[3].y};
+            st.raw[0][0][5 + 2 * yb] = v4{hi[0].y, hi[1].y, hi[2].y, hi[3].y};
+            NDWT_SCHED_FENCE();
+        NDWT_SEND
+    }
+
+    template <class Exec> static NDWT_DEV void block(Exec& ex, Shared& sh, const Args& a, const Taps& tpm, int bid) {
+        typename Y::RegTaps tp;
+        Y::load_taps(tp, tpm.syn);
+        RegTapsA ta;
+        load_taps_a(ta, tpm);
+        const TileCoord tc = decode_tile(a, bid, TX, TY);
+        const int nsteps = tc.zend - tc.zbeg;
+        const int nplanes = nsteps + L - 1;              // coefficient planes zbeg - LH .. zend - 1 + RH of the synthesis
+        const int zc0 = tc.zbeg - Y::LH;
+        ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+            Y::setup(st, a, tc, tid);
+            setup_a(st, a, tc, tid);
+            NDWT_SFOR(j, L - 1)                           // raw planes zc0 - ALH .. zc0 + ARH - 1 into window slots 0 .. L-2
+                load_x(st, a, zc0 - ALH + j);
+                st.win[j] = st.nxt;
+            NDWT_SEND
+            load_x(st, a, zc0 + ARH);
+            load_apx(st, a, zc0);
+        });
+        ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+            zdispatch_a<0>(0, st, sh, ta, tid);
+            if (nplanes > 1) load_x(st, a, zc0 + 1 + ARH);
+        });
+        ex.barrier();
+        for (int p = 0; p < nplanes; ++p) {
+            ex.each([&](int tid, State& st) __attribute__((always_inline)) { yana(st, sh, ta, tid); });
+            ex.each([&](int tid, State& st) __attribute__((always_inline)) { xana(ex, st, ta, tid); });
+            ex.each([&](int, State& st) __attribute__((always_inline)) {
+                NDWT_SFOR(b, 7)                           // the seven detail bands, thresholded where they are
+                    shrink4<T, 1>(st.raw[0][0][b + 1], a.shrink_thr, a.shrink_hard);
+                NDWT_SEND
+                st.raw[0][0][0] = st.apx;                 // band 0: the approximation the deeper levels reconstructed
+                if (p + 1 < nplanes) load_apx(st, a, zc0 + p + 1);
+            });
+            ex.each([&](int tid, State& st) __attribute__((always_inline)) { Y::template xsyn<0>(ex, st, sh, tp, p & 1, tid); });
+            ex.barrier();
+            const int s = p - (L - 1);
+            NDWT_SETPRIO(1);
+            ex.each([&](int tid, State& st) __attribute__((always_inline)) { Y::ysyn(st, sh, tp, p & 1, tid); });
+            ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+                Y::template zdispatch<0>((p + 1) % L, st, sh, tp, a, 0LL, tc.zbeg + s, s >= 0, tid);
+            });
+            NDWT_SETPRIO(0);
+            if (p + 1 < nplanes) {
+                ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+                    zdispatch_a<0>((p + 1) % L, st, sh, ta, tid);
+                    if (p + 2 < nplanes) load_x(st, a, zc0 + p + 2 + ARH);
+                });
+                ex.barrier();
             }
         }
     }

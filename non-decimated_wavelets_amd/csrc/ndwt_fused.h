@@ -28,6 +28,11 @@ int launch_inv3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4,
 int launch_inv3y_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, const void* taps_dev, hipStream_t s);
 int launch_inv3yc_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, const void* taps_dev, hipStream_t s);   // interleaved complex
 
+// level 1 of a denoising step in one launch (Den3: in[0] = x, in[1] = approximation band) and the approximation-only analysis
+// that goes with it (tall 64 x 32 tile); float, real data, tap lengths 2 .. 8: ndwt_fused3_f32_den.hip
+int launch_den3_f32(const Fused3Args<float>& a, int Lp, const void* taps_dev, hipStream_t s);
+int launch_fwd3_low_f32(const Fused3Args<float>& a, int Lp, bool vec4, const void* taps_dev, hipStream_t s);
+
 // float, tap lengths 14..18 (analysis) / 14..16 (synthesis): ndwt_fused3_f32_long.hip
 int launch_long3_f32(bool inverse, const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, int variant, const void* taps_dev, hipStream_t s);
 

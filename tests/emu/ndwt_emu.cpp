@@ -421,6 +421,73 @@ int emu_yc_small(int depth, int Lp, int vec4, ndwt::Fused3Args<float>& a, const 
 }
 #endif
 
+#if EMU_IN(13)
+// level 1 of a denoising step in one launch (Den3) and the approximation-only analysis (Fwd3<.., LOWONLY>), production tile
+template <int LL>
+static int run_den3(ndwt::Fused3Args<float>& a, const double* slo, const double* shi, const double* alo, const double* ahi) {
+    typedef ndwt::Den3<float, LL, 1024, 4> K;
+    std::unique_ptr<typename K::Taps> tp(new typename K::Taps);
+    for (int ax = 0; ax < 3; ++ax)
+        for (int j = 0; j < LL; ++j) {
+            tp->syn.lo[ax][j] = (float)slo[ax * ndwt::kMaxTaps + j];
+            tp->syn.hi[ax][j] = (float)shi[ax * ndwt::kMaxTaps + j];
+            tp->alo[ax][j] = (float)alo[ax * ndwt::kMaxTaps + j];
+        }
+    for (int k = 0; k <= LL; ++k)
+        for (int h = 0; h < 2; ++h) {
+            const int j = k - h;
+            tp->syn.xplo[k][h] = (j >= 0 && j < LL) ? (float)slo[j] : 0.0f;
+            tp->syn.xphi[k][h] = (j >= 0 && j < LL) ? (float)shi[j] : 0.0f;
+        }
+    for (int j = 0; j < LL; ++j) {
+        tp->azp[j][0] = (float)alo[2 * ndwt::kMaxTaps + j];
+        tp->azp[j][1] = (float)ahi[2 * ndwt::kMaxTaps + j];
+    }
+    const int nblocks = a.ntx * a.nty * a.nzc * a.nbatch;
+    for (int b = 0; b < nblocks; ++b) {
+        std::unique_ptr<typename K::Shared> sh(new typename K::Shared);
+        EmuExec<typename K::State, K::NT> ex;
+        K::block(ex, *sh, a, *tp, b);
+    }
+    return 0;
+}
+template <int LL, bool V> static int run_low3(ndwt::Fused3Args<float>& a, const double* lo, const double* hi) {
+    typedef ndwt::Fused3Tile<float, false, 2> TL;
+    return run<ndwt::Fwd3<float, LL, TL::TX, TL::TY, TL::NT, TL::RY, V, 2, 1, true>, float>(a, lo, hi);
+}
+extern "C" int ndwt_emu_den3_f32(int Lp, const float* x, const float* apx, float* out, int n1, int n2, int n3, int zchunk,
+                                 const double* slo, const double* shi, const double* alo, const double* ahi, double thr, int hard) {
+    ndwt::Fused3Args<float> a;
+    std::memset(&a, 0, sizeof(a));
+    a.n1 = n1; a.n2 = n2; a.n3 = n3; a.nbatch = 1; a.z_wrap = 1;
+    a.in[0] = x; a.in[1] = apx; a.out[0] = out;
+    a.shrink_thr = (float)thr; a.shrink_mask = 0xFE; a.shrink_hard = hard;
+    ndwt::fused3_geometry(a, 64, 32, 2 * Lp - 1, 4, zchunk);
+    switch (Lp) {
+        case 2: return run_den3<2>(a, slo, shi, alo, ahi);
+        case 4: return run_den3<4>(a, slo, shi, alo, ahi);
+        case 6: return run_den3<6>(a, slo, shi, alo, ahi);
+        case 8: return run_den3<8>(a, slo, shi, alo, ahi);
+        default: return -1;
+    }
+}
+extern "C" int ndwt_emu_low3_f32(int Lp, int vec4, const float* x, float* out, int n1, int n2, int n3, int zchunk, const double* alo,
+                                 const double* ahi) {
+    ndwt::Fused3Args<float> a;
+    std::memset(&a, 0, sizeof(a));
+    a.n1 = n1; a.n2 = n2; a.n3 = n3; a.nbatch = 1; a.z_wrap = 1;
+    a.in[0] = x; a.out[0] = out;
+    ndwt::fused3_geometry(a, 64, 32, Lp, 4, zchunk);
+    switch (Lp) {
+        case 2: return vec4 ? run_low3<2, true>(a, alo, ahi) : run_low3<2, false>(a, alo, ahi);
+        case 4: return vec4 ? run_low3<4, true>(a, alo, ahi) : run_low3<4, false>(a, alo, ahi);
+        case 6: return vec4 ? run_low3<6, true>(a, alo, ahi) : run_low3<6, false>(a, alo, ahi);
+        case 8: return vec4 ? run_low3<8, true>(a, alo, ahi) : run_low3<8, false>(a, alo, ahi);
+        default: return -1;
+    }
+}
+#endif
+
 extern "C" {
 #if EMU_IN(1)
 int ndwt_emu_axisx_f32(int syn, int L, int ew, int vec4, const float* in0, const float* in1, float* out0, float* out1, long long row,

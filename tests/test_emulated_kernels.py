@@ -415,3 +415,66 @@ def test_emulated_dilated_2d_level_on_row_sublattices(emu, sizes, wn, dtype):
     want_r = orc.spatial_level_rec(c, filt, 0, 2)
     got = _run2(emu, c, wn, 0, True, dtype, True, 5, dil=2)
     assert np.isfinite(got).all() and np.abs(got - want_r).max() <= tol * max(np.abs(want_r).max(), 1.0)
+
+
+def _taps3(wname, l2, L):
+    t = kernel_taps(wname, l2, L)
+    arr = {k: np.zeros((3, 20)) for k in t}
+    for k in t:
+        arr[k][:, :L] = t[k]
+    return arr
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("sizes,wname,zchunk", [
+    ((68, 36, 9), "db4", 0),          # ragged in x and y: 2 x 2 production tiles
+    ((72, 33, 20), "db4", 7),         # several z chunks
+    ((64, 32, 5), "db3", 0),
+    ((12, 10, 6), "db2", 0),          # a volume smaller than the halo: every axis wraps more than once
+    ((76, 40, 7), "db1", 3),
+])
+@pytest.mark.parametrize("l2,hard", [(1, 0), (0, 1)])
+def test_emulated_fused_level1_denoise(emu, sizes, wname, zchunk, l2, hard):
+    """Den3: level 1 of dec -> shrink -> rec in one launch -- the detail bands are recomputed from x on the haloed tile, thresholded in
+    registers and synthesised together with a given approximation band (reference: one level of nd_dwt_3D.m:345-374 each way)"""
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal(sizes)
+    apx = rng.standard_normal(sizes)
+    filt = [orc.wave_filters(wname)] * 3
+    c = orc.spatial_level_dec(x, filt, l2)
+    c = _np_shrink_bands(c, 0.6, hard, 0xFE)
+    c[..., 0] = apx
+    want = orc.spatial_level_rec(c, filt, l2)
+    L = len(filt[0][0])
+    t = _taps3(wname, l2, L)
+    xs, aps = to_kernel_order(x).astype(np.float32), to_kernel_order(apx).astype(np.float32)
+    n3, n2, n1 = xs.shape
+    out = np.full((n3, n2, n1), np.nan, dtype=np.float32)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rc = emu.ndwt_emu_den3_f32(L, p(xs), p(aps), p(out), n1, n2, n3, zchunk, p(t["syn_lo"]), p(t["syn_hi"]), p(t["ana_lo"]), p(t["ana_hi"]),
+                               ctypes.c_double(0.6), hard)
+    assert rc == 0
+    got = np.transpose(out)
+    assert np.isfinite(got).all()
+    # hard thresholding is discontinuous: a coefficient within rounding of the threshold may fall on the other side in fp32
+    bad = np.abs(got - want) > 4e-6 * max(np.abs(want).max(), 1.0)
+    assert bad.mean() <= (2e-3 if hard else 0.0), float(np.abs(got - want).max())
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("sizes,wname,vec4,zchunk", [((68, 36, 9), "db4", True, 0), ((70, 33, 12), "db3", False, 5), ((64, 32, 6), "db1", True, 0)])
+def test_emulated_approximation_only_analysis(emu, sizes, wname, vec4, zchunk):
+    """Fwd3<.., LOWONLY>: band 0 of one analysis level, the other seven neither computed through nor stored"""
+    rng = np.random.default_rng(32)
+    x = rng.standard_normal(sizes)
+    filt = [orc.wave_filters(wname)] * 3
+    want = orc.spatial_level_dec(x, filt, 1)[..., 0]
+    L = len(filt[0][0])
+    t = _taps3(wname, 1, L)
+    xs = to_kernel_order(x).astype(np.float32)
+    n3, n2, n1 = xs.shape
+    out = np.full((n3, n2, n1), np.nan, dtype=np.float32)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    assert emu.ndwt_emu_low3_f32(L, int(vec4), p(xs), p(out), n1, n2, n3, zchunk, p(t["ana_lo"]), p(t["ana_hi"])) == 0
+    got = np.transpose(out)
+    assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()

@@ -876,3 +876,38 @@ def test_three_ranks_share_one_gpu_over_gloo():
     for rank, errs in res:
         for e_dec, e_rec in errs:
             assert e_dec <= 2e-6 and e_rec <= 1e-5, (rank, errs)
+
+
+@pytest.mark.parametrize("sizes,wn,level", [
+    ([64, 32, 16], "db4", 3),            # one tile
+    ([72, 40, 33], "db4", 2),            # ragged tiles, odd plane count
+    ([132, 70, 20], "db3", 3),
+    ([128, 64, 64], "db2", 1),           # a single level: the approximation goes straight from the band-0 analysis to Den3
+    ([68, 36, 9], "db1", 2),
+    ([16, 12, 10], "db4", 2),            # smaller than the tile and its halo: every axis wraps
+])
+@pytest.mark.parametrize("l2", [0, 1])
+def test_denoise_with_fused_level1_against_numpy(sizes, wn, level, l2):
+    """ndwt_denoise where the finest level never materialises its detail bands (Den3: recomputed from x, thresholded in registers)
+    against dec -> shrink -> rec of the oracle and against the library's own materialising path"""
+    rng = np.random.default_rng(41)
+    x = rng.standard_normal(sizes)
+    w = ndwt.nd_dwt_3D(wn, sizes, "pres_l2_norm", l2, "precision", "single")
+    xg = _colmajor_gpu(x, "single")
+    wl = [wn] * 3
+    y_ref = orc.spatial_dec(x, wl, level, l2)
+    thr = 0.35 * (8.0 ** 0.5 if not l2 else 1.0)
+    for mode in ("soft", "hard"):
+        got = w.denoise(xg, level, thr, mode)
+        plan = list(w._plans.values())[0]
+        plan.set_fused_level1(False)
+        mat = w.denoise(xg, level, thr, mode)
+        plan.set_fused_level1(True)
+        want = orc.spatial_rec(_np_shrink(y_ref, thr, mode == "hard"), wl, l2)
+        scale = max(np.abs(want).max(), 1.0)
+        # hard thresholding is discontinuous: coefficients within rounding of the threshold may fall on either side in fp32
+        frac = 2e-3 if mode == "hard" else 0.0
+        for name, a in (("numpy", want), ("materialised", mat.cpu().numpy())):
+            bad = np.abs(got.cpu().numpy() - a) > 2e-5 * scale
+            assert bad.mean() <= frac, (name, mode, float(np.abs(got.cpu().numpy() - a).max()))
+    assert _relerr(w.denoise(xg, level, 0.0).cpu().numpy(), x) < 20 * TOL["single"]      # threshold 0 = identity
