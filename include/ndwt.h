@@ -93,8 +93,9 @@ int ndwt_plan_set_tuning(ndwt_plan* plan, int target_blocks, int force_zchunk);
  * fused (1) or per-axis (0) kernels.  Negative = leave unchanged.  Every variant computes the same values; the library never
  * reads the environment. */
 int ndwt_plan_set_variant(ndwt_plan* plan, int variant_fwd, int variant_inv, int zchunk_fwd, int zchunk_inv, int fp64_fused);
-/* test / tuning hook: enable = 0 makes ndwt_denoise keep the level-1 detail bands in memory (dec, thresholding fused into the
- * synthesis loads, rec); 1 (default) = level 1 in one launch that recomputes them (float, real, 3-D, one tap length <= 8). */
+/* test / tuning hook: 0 makes ndwt_denoise keep the level-1 detail bands in memory (dec, thresholding fused into the synthesis
+ * loads, rec); 1 (default) = level 1 in one launch that recomputes them where that is faster (float, real, 3-D, one tap length
+ * <= 6 on every axis); 2 = also with 8 taps (compute-bound there: 3 % slower than the materialising path at 512^3). */
 int ndwt_plan_set_fused_level1(ndwt_plan* plan, int enable);
 /* per-kernel timing with HIP events recorded on the launch stream around every kernel this plan launches
  * (what bench.py's roofline line is computed from).  ndwt_plan_get_profile() synchronises the device, sums and
@@ -130,7 +131,7 @@ int ndwt_rec_host(ndwt_plan* plan, const void* y_host, void* x_host, int level);
  *   coarsest approximation, is kept); complex data: the magnitude is shrunk, the phase kept.
  * ndwt_denoise: dec -> shrink -> rec in one call; the coefficients live in a scratch array owned by the plan, so only
  *   the signal crosses the boundary (x and out may be the same buffer).  The host form moves 2 x prod(dims) elements
- *   over PCIe instead of 2 x prod(dims) x bands.  Float, real, 3-D plans with one tap length <= 8 on every axis and
+ *   over PCIe instead of 2 x prod(dims) x bands.  Float, real, 3-D plans with one tap length <= 6 on every axis and
  *   16-byte aligned, non-overlapping x / out run the FINEST LEVEL WITHOUT ITS DETAIL BANDS IN MEMORY: one launch recomputes
  *   them from x, thresholds them in registers and reconstructs (5 volumes moved at level 1 instead of 18); the values are
  *   those of dec -> shrink -> rec up to fp32 rounding (the recomputed coefficients are not rounded through memory).

@@ -74,9 +74,10 @@ class Plan:
         L.check(L.lib().ndwt_plan_set_variant(self._h, int(fwd), int(inv), int(zchunk_fwd), int(zchunk_inv), int(fp64_fused)))
         return self
 
-    def set_fused_level1(self, on: bool):
-        """tuning hook: False = denoise() keeps the level-1 detail bands in memory (the round-2 path)"""
-        L.check(L.lib().ndwt_plan_set_fused_level1(self._h, int(bool(on))))
+    def set_fused_level1(self, mode):
+        """tuning hook: 0 / False = denoise() keeps the level-1 detail bands in memory; 1 / True (default) = level 1 in one launch where
+        that is faster (tap lengths <= 6); 2 = wherever the kernel exists (8 taps too)"""
+        L.check(L.lib().ndwt_plan_set_fused_level1(self._h, int(mode)))
         return self
 
     def set_variant_from_env(self):

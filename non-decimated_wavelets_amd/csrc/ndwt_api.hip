@@ -93,7 +93,8 @@ struct ndwt_plan {
     void* coef;                        // coefficient scratch of ndwt_denoise (all bands of the last level used), lazily allocated
     size_t coef_bytes;
     void* taps_den;                    // device tap table of the fused level-1 denoising kernel (TapsDen<float, L>), lazily built
-    int no_fused_level1;               // tuning hook: ndwt_denoise keeps the level-1 detail bands in memory (the round-2 path)
+    int fused_level1;                  // ndwt_denoise: 1 (default) level 1 in one launch where that is faster (tap lengths <= 6), 2 wherever the
+                                       // kernel exists (8 taps too: compute-bound there, +3 %), 0 never (the level-1 detail bands stay in memory)
     // optional per-kernel timing with HIP events on the launch stream (bench.py's roofline figures)
     int profiling;
     std::vector<ProfRec>* prof;
@@ -919,6 +920,7 @@ static int plan_create_impl(ndwt_plan** plan, int ndim, const int64_t* dims, lon
     p->target_blocks = 0;
     p->prof = new std::vector<ProfRec>();
     p->ev_pool = new std::vector<hipEvent_t>();
+    p->fused_level1 = 1;
     p->fp64_fused = 1;   // measured: 256^3 fp64 db4 L3 2.5 ms fused (LDS analysis + lane-shift synthesis) vs 4.1 ms per-axis
     static const char* ordn[4] = {"First", "Second", "Third", "Fourth"};
     p->vol = p->comp;
@@ -1091,10 +1093,10 @@ int ndwt_plan_set_variant(ndwt_plan* p, int variant_fwd, int variant_inv, int zc
 }
 
 // test / tuning hook: 0 = ndwt_denoise materialises the level-1 detail bands (dec, thresholding in the synthesis loads, rec);
-// 1 (default) = the fused level-1 kernel wherever it applies
+// 1 (default) = the fused level-1 kernel where it is the faster path (tap lengths <= 6); 2 = wherever it exists (8 taps too)
 int ndwt_plan_set_fused_level1(ndwt_plan* p, int enable) {
     if (!p) return fail(NDWT_ERR_INVALID_ARG, "null plan");
-    p->no_fused_level1 = enable ? 0 : 1;
+    p->fused_level1 = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
     return NDWT_OK;
 }
 
@@ -1215,10 +1217,13 @@ int ndwt_shrink(ndwt_plan* p, void* y, int level, double threshold, int mode, vo
 // ---- level 1 of a denoising step without its detail bands in memory (Den3, ndwt_device.h) ----
 // Float, real, 3-D, reference dilation, the same tap length L <= 8 on every axis, rows of whole 16-byte groups.
 static bool den3_eligible(const ndwt_plan* p, int* Lp_out) {
-    if (p->no_fused_level1 || p->dtype != NDWT_F32 || p->complexity != NDWT_REAL || p->ndim != 3 || p->dilation != NDWT_DILATION_REFERENCE)
+    if (!p->fused_level1 || p->dtype != NDWT_F32 || p->complexity != NDWT_REAL || p->ndim != 3 || p->dilation != NDWT_DILATION_REFERENCE)
         return false;
     int Lp = 0;
-    if (!fused3_eligible(p, 1, &Lp) || Lp > 8 || !inv3y_plan_ok(p, Lp)) return false;
+    // measured, 512^3, 3 levels, ndwt_denoise with / without the fused level 1: db1 4.49 / 5.27 ms, db2 5.10 / 5.67, db3 5.72 / 6.09,
+    // db4 6.30 / 6.13 -- with 8 taps the recomputation (2.3x the arithmetic of the synthesis kernel, 67 % VALU-busy) costs more than the
+    // 13 volume transfers it removes, so 8 taps take the kernel only when asked to (ndwt_plan_set_fused_level1(plan, 2))
+    if (!fused3_eligible(p, 1, &Lp) || Lp > (p->fused_level1 >= 2 ? 8 : 6) || !inv3y_plan_ok(p, Lp)) return false;
     for (int ax = 0; ax < 3; ++ax)
         if (p->filt[ax].len != Lp) return false;
     if (p->dims[0] % 4 != 0) return false;
@@ -1229,7 +1234,7 @@ static bool den3_eligible(const ndwt_plan* p, int* Lp_out) {
 static int den3_taps(ndwt_plan* p, int Lp) {
     if (p->taps_den) return NDWT_OK;
     const FusedTapsD ts = fused_taps(p, Lp, true), ta = fused_taps(p, Lp, false);
-    std::vector<float> h;                                 // TapsDen<float, Lp>: Taps3Y (lo[3][L], hi[3][L], xplo[L+1][2], xphi[L+1][2]), alo[3][L], azp[L][2]
+    std::vector<float> h;                                 // TapsDen<float, Lp>: Taps3Y (lo[3][L], hi[3][L], xplo[L+1][2], xphi[L+1][2]), alo[3][L], azp[L][2], axp[L+1][2]
     for (int ax = 0; ax < 3; ++ax) for (int j = 0; j < Lp; ++j) h.push_back((float)ts.lo[ax][j]);
     for (int ax = 0; ax < 3; ++ax) for (int j = 0; j < Lp; ++j) h.push_back((float)ts.hi[ax][j]);
     for (int hi = 0; hi < 2; ++hi)
@@ -1240,6 +1245,11 @@ static int den3_taps(ndwt_plan* p, int Lp) {
             }
     for (int ax = 0; ax < 3; ++ax) for (int j = 0; j < Lp; ++j) h.push_back((float)ta.lo[ax][j]);
     for (int j = 0; j < Lp; ++j) { h.push_back((float)ta.lo[2][j]); h.push_back((float)ta.hi[2][j]); }
+    for (int k = 0; k <= Lp; ++k)                         // axp[L+1][2]: (alo_x[k], alo_x[k-1])
+        for (int hh = 0; hh < 2; ++hh) {
+            const int j = k - hh;
+            h.push_back((j >= 0 && j < Lp) ? (float)ta.lo[0][j] : 0.0f);
+        }
     // the kernel derives the analysis high-pass taps of x and y from the low-pass ones: ahi[j] = (-1)^j alo[L-1-j]
     for (int ax = 0; ax < 2; ++ax)
         for (int j = 0; j < Lp; ++j)
@@ -1270,7 +1280,9 @@ static int den3_launch(ndwt_plan* p, int kind, int Lp, const float* x, const flo
         a.shrink_hard = p->shrink_mode == 2;
     }
     // one workgroup per CU (1024 threads); Den3's march starts 2 (L - 1) planes before its first output plane
-    fused3_geometry(a, 64, 32, kind == 1 ? 2 * Lp - 1 : Lp, p->target_blocks > 0 ? p->target_blocks : p->num_cus, p->force_zchunk);
+    const bool small_tile = kind == 0 && p->variant_fwd != 2 && a.n2 > 16;   // the band-0 analysis on 64 x 16 tiles, 3 workgroups per CU (0.36 vs 0.42 ms; variant 2: A/B)
+    if (small_tile) fused3_geometry(a, 64, 16, Lp, p->target_blocks > 0 ? p->target_blocks : p->num_cus * 3, p->force_zchunk);
+    else fused3_geometry(a, 64, 32, kind == 1 ? 2 * Lp - 1 : Lp, p->target_blocks > 0 ? p->target_blocks : p->num_cus, p->force_zchunk);
     float* outs[1] = {out};
     a.nt = nt_store_ok<float>(a.rs, a.plane, p->vol, outs, 1);
     prof_begin(p, kind == 1 ? NDWT_KERNEL_FUSED_SYNTHESIS : NDWT_KERNEL_FUSED_ANALYSIS, s);

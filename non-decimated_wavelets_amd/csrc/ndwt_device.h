@@ -106,6 +106,27 @@ template <typename T, int EW, class V4> NDWT_DEV void shrink4(V4& c, T thr, int 
     }
 }
 
+// the same thresholding of real data without divergent branches (Den3 thresholds 28 values per lane and plane): soft
+// v - clamp(v, -t, t) (the same subtraction / addition shrink4 performs, so the same bits), hard |v| > t ? v : 0; `hard` is uniform
+template <typename T, class V4> NDWT_DEV void shrink4_flat(V4& c, T thr, int hard) {
+    if (hard) {
+        NDWT_SFOR(e, 4)
+            const T v = c[e];
+            c[e] = (v < T(0) ? -v : v) > thr ? v : T(0);
+        NDWT_SEND
+    } else {
+        NDWT_SFOR(e, 4)
+            const T v = c[e];
+#if !defined(NDWT_HOST_EMU)
+            if constexpr (sizeof(T) == 4) c[e] = v - __builtin_amdgcn_fmed3f(v, -thr, thr);
+            else c[e] = v - (v < -thr ? -thr : (v > thr ? thr : v));
+#else
+            c[e] = v - (v < -thr ? -thr : (v > thr ? thr : v));
+#endif
+        NDWT_SEND
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Axis kernels (general path).  Array viewed as [outer][N][inner], inner contiguous.
 // ------------------------------------------------------------------------------------------------
@@ -1592,14 +1613,15 @@ template <typename T, int L> struct TapsDen {
     Taps3Y<T, L> syn;        // synthesis taps, the table of Inv3Y
     T alo[3][L];             // analysis low-pass taps (x, y, z); the high-pass ones are derived: ahi[j] = (-1)^j alo[L-1-j]
     T azp[L][2];             // (alo_z[j], ahi_z[j]): the z stage produces (lo, hi) pairs from one broadcast sample
+    T axp[L + 1][2];         // (alo_x[k], alo_x[k-1]), k = 0..L, taps outside [0, L) = 0: the x stage works on pairs of adjacent x
 };
 
-template <typename T, int L_, int NT_ = 1024, int WPE_ = 4> struct Den3 {
+template <typename T, int L_, int NT_ = 1024, int WPE_ = 4, int ZLDS_ = 0> struct Den3 {
     static_assert(sizeof(T) == 4, "float only");
     static constexpr int L = L_, TX = 64, TY = 32, NT = NT_, WPE = WPE_;
     static constexpr int ALH = L / 2 - 1, ARH = L / 2;   // analysis: samples left / right of the output index
     static constexpr int XH = (ARH + 3) / 4;             // extra lanes per side of a haloed row
-    typedef Inv3Y<T, L, TX, TY, NT, true, WPE, 1, 1, 0, XH> Y;
+    typedef Inv3Y<T, L, TX, TY, NT, true, WPE, 1, 1, ZLDS_, XH> Y;   // (ZLDS_ of the L pending z sums in LDS: Inv3Y)
     static constexpr int NG = Y::NG, RPW = Y::RPW, NW = NT / 64;
     static constexpr int NRS = Y::NR;                    // rows of coefficients under the tile (TY + L - 1)
     static constexpr int NRA = NRS + L - 1;              // rows of raw samples under those
@@ -1623,17 +1645,26 @@ template <typename T, int L_, int NT_ = 1024, int WPE_ = 4> struct Den3 {
         unsigned aoff;             // byte offset of the z-stage row inside a plane (kNoRow: this lane holds none)
     };
     struct RegTapsA {
-        v2 ax[L / 2], ay[L / 2];   // (alo[2m], alo[2m+1]) of the x and y axes
+        v2 xp[L + 1];              // (alo_x[k], alo_x[k-1])
+        v2 ay[L / 2];              // (alo_y[2m], alo_y[2m+1])
         v2 az[L];                  // (alo_z[j], ahi_z[j])
     };
     static NDWT_DEV void load_taps_a(RegTapsA& ta, const Taps& tp) {
+        NDWT_SFOR(k, L + 1)
+            ta.xp[k] = Y::pinned(v2{tp.axp[k][0], tp.axp[k][1]});
+        NDWT_SEND
         NDWT_SFOR(m, L / 2)
-            ta.ax[m] = Y::pinned(v2{tp.alo[0][2 * m], tp.alo[0][2 * m + 1]});
             ta.ay[m] = Y::pinned(v2{tp.alo[1][2 * m], tp.alo[1][2 * m + 1]});
         NDWT_SEND
         NDWT_SFOR(j, L)
             ta.az[j] = Y::pinned(v2{tp.azp[j][0], tp.azp[j][1]});
         NDWT_SEND
+    }
+    // acc(e, e+1) += (t[K], t[K-1]) * w[H]: the x taps of two adjacent outputs for one window entry.  Low-pass: the pair xp[K].
+    // High-pass: (ahi[K], ahi[K-1]) = ((-1)^K alo[L-1-K], (-1)^(K-1) alo[L-K]) = the halves of xp[L-K] swapped, one negated.
+    template <int H, int K, bool HIGH> static NDWT_DEV void xtap_a(v2& acc, const v2 w, const RegTapsA& ta) {
+        if constexpr (!HIGH) Y::template pk_fma_bt<H, false, false, false>(acc, w, ta.xp[K]);
+        else Y::template pk_fma_bt<H, true, K % 2 != 0, K % 2 == 0>(acc, w, ta.xp[L - K]);
     }
     // acc += x * analysis low-pass tap J (HIGH = false) or high-pass tap J = (-1)^J low-pass tap L-1-J
     template <int J, bool HIGH> static NDWT_DEV void tap_a(v2& acc, const v2 x, const v2 (&lo)[L / 2]) {
@@ -1663,14 +1694,14 @@ template <typename T, int L_, int NT_ = 1024, int WPE_ = 4> struct Den3 {
             st.win[j] = (v4)(T(0));
         NDWT_SEND
     }
-    static NDWT_DEV void load_x(State& st, const Args& a, int zraw) {
-        const long long zm = (long long)modn(zraw, a.n3);
-        if (st.aoff != Y::kNoRow) st.nxt = Y::template gload<v4>(a.in[0] + zm * a.plane, st.aoff);
+    // zm: plane index inside the volume (the caller wraps it: one compare per plane instead of a division)
+    static NDWT_DEV void load_x(State& st, const Args& a, int zm) {
+        if (st.aoff != Y::kNoRow) st.nxt = Y::template gload<v4>(a.in[0] + (long long)zm * a.plane, st.aoff);
     }
-    static NDWT_DEV void load_apx(State& st, const Args& a, int zc) {
-        const long long zm = (long long)modn(zc, a.n3);
-        if (st.off[0][0] != Y::kNoRow) st.apx = Y::template gload<v4>(a.in[1] + zm * a.plane, st.off[0][0]);
+    static NDWT_DEV void load_apx(State& st, const Args& a, int zm) {
+        if (st.off[0][0] != Y::kNoRow) st.apx = Y::template gload<v4>(a.in[1] + (long long)zm * a.plane, st.off[0][0]);
     }
+    static NDWT_DEV int next_plane(int zm, int n3) { return zm + 1 == n3 ? 0 : zm + 1; }
 
     // z analysis of the newest raw plane: rotation R puts it into slot (R+L-1)%L, tap j reads slot (R+j)%L (Fwd3::zstage)
     template <int R> static NDWT_DEV void zana(State& st, Shared& sh, const RegTapsA& ta, int tid) {
@@ -1726,28 +1757,33 @@ template <typename T, int L_, int NT_ = 1024, int WPE_ = 4> struct Den3 {
     // the results are the eight bands of the lane's 4 x, in the registers the synthesis x stage reads (band = x-bit + 2 y-bit + 4 z-bit)
     template <class Exec> static NDWT_DEV void xana(Exec& ex, State& st, const RegTapsA& ta, int tid) {
         NDWT_SFOR(yb, 2)
-            v2 lo[4], hi[4];
-            NDWT_SFOR(e, 4)
-                lo[e] = (v2)(T(0));
-                hi[e] = (v2)(T(0));
+            v2 acc[2][2][2];                              // [x-bit][z-bit][outputs (0,1) / (2,3)]: pairs of adjacent x, like Inv3Y::xsyn
+            NDWT_SFOR(q, 8)
+                acc[q / 4][(q / 2) % 2][q % 2] = (v2)(T(0));
             NDWT_SEND
             NDWT_SFOR(ii, 4 + L - 1)
                 constexpr int i = ii - ALH;                // x offset of the window entry from the lane's first x
                 constexpr int D = i < 0 ? -1 : (i >= 4 ? 1 : 0);
                 constexpr int c = (i + 4) % 4;
-                const v2 w = {NDWT_LANE_SHIFT(ex, tid, D, s.ya[yb][c].x), NDWT_LANE_SHIFT(ex, tid, D, s.ya[yb][c].y)};
-                NDWT_SFOR(e, 4)
-                    constexpr int j = i - e + ALH;
-                    if constexpr (j >= 0 && j < L) {
-                        tap_a<j, false>(lo[e], w, ta.ax);
-                        tap_a<j, true>(hi[e], w, ta.ax);
+                constexpr int K01 = i + ALH, K23 = i - 2 + ALH;      // tap-pair index of this entry for outputs (0,1) / (2,3)
+                constexpr bool u01 = K01 >= 0 && K01 <= L, u23 = K23 >= 0 && K23 <= L;
+                const v2 w = {NDWT_LANE_SHIFT(ex, tid, D, s.ya[yb][c].x), NDWT_LANE_SHIFT(ex, tid, D, s.ya[yb][c].y)};   // (z-bit 0, z-bit 1)
+                NDWT_SFOR(zb, 2)
+                    if constexpr (u01) {
+                        if constexpr (yb + zb != 0) xtap_a<zb, u01 ? K01 : 0, false>(acc[0][zb][0], w, ta);   // (band 0 is not used: the
+                        xtap_a<zb, u01 ? K01 : 0, true>(acc[1][zb][0], w, ta);                                  //  approximation replaces it)
+                    }
+                    if constexpr (u23) {
+                        if constexpr (yb + zb != 0) xtap_a<zb, u23 ? K23 : 0, false>(acc[0][zb][1], w, ta);
+                        xtap_a<zb, u23 ? K23 : 0, true>(acc[1][zb][1], w, ta);
                     }
                 NDWT_SEND
             NDWT_SEND
-            st.raw[0][0][0 + 2 * yb] = v4{lo[0].x, lo[1].x, lo[2].x, lo[3].x};
-            st.raw[0][0][1 + 2 * yb] = v4{hi[0].x, hi[1].x, hi[2].x, hi[3].x};
-            st.raw[0][0][4 + 2 * yb] = v4{lo[0].y, lo[1].y, lo[2].y, lo[3].y};
-            st.raw[0][0][5 + 2 * yb] = v4{hi[0].y, hi[1].y, hi[2].y, hi[3].y};
+            NDWT_SFOR(xb, 2)
+                NDWT_SFOR(zb, 2)
+                    st.raw[0][0][xb + 2 * yb + 4 * zb] = v4{acc[xb][zb][0].x, acc[xb][zb][0].y, acc[xb][zb][1].x, acc[xb][zb][1].y};
+                NDWT_SEND
+            NDWT_SEND
             NDWT_SCHED_FENCE();
         NDWT_SEND
     }
@@ -1761,31 +1797,42 @@ template <typename T, int L_, int NT_ = 1024, int WPE_ = 4> struct Den3 {
         const int nsteps = tc.zend - tc.zbeg;
         const int nplanes = nsteps + L - 1;              // coefficient planes zbeg - LH .. zend - 1 + RH of the synthesis
         const int zc0 = tc.zbeg - Y::LH;
+        int zx = modn(zc0 - ALH, a.n3);                  // next raw plane / next approximation plane, wrapped into the volume
+        int za = modn(zc0, a.n3);
         ex.each([&](int tid, State& st) __attribute__((always_inline)) {
             Y::setup(st, a, tc, tid);
             setup_a(st, a, tc, tid);
-            NDWT_SFOR(j, L - 1)                           // raw planes zc0 - ALH .. zc0 + ARH - 1 into window slots 0 .. L-2
-                load_x(st, a, zc0 - ALH + j);
-                st.win[j] = st.nxt;
-            NDWT_SEND
-            load_x(st, a, zc0 + ARH);
-            load_apx(st, a, zc0);
         });
+        NDWT_SFOR(j, L - 1)                               // raw planes zc0 - ALH .. zc0 + ARH - 1 into window slots 0 .. L-2
+            ex.each([&](int, State& st) __attribute__((always_inline)) {
+                load_x(st, a, zx);
+                st.win[j] = st.nxt;
+            });
+            zx = next_plane(zx, a.n3);
+        NDWT_SEND
+        ex.each([&](int, State& st) __attribute__((always_inline)) {
+            load_x(st, a, zx);
+            load_apx(st, a, za);
+        });
+        zx = next_plane(zx, a.n3);
+        za = next_plane(za, a.n3);
         ex.each([&](int tid, State& st) __attribute__((always_inline)) {
             zdispatch_a<0>(0, st, sh, ta, tid);
-            if (nplanes > 1) load_x(st, a, zc0 + 1 + ARH);
+            if (nplanes > 1) load_x(st, a, zx);
         });
+        zx = next_plane(zx, a.n3);
         ex.barrier();
         for (int p = 0; p < nplanes; ++p) {
             ex.each([&](int tid, State& st) __attribute__((always_inline)) { yana(st, sh, ta, tid); });
             ex.each([&](int tid, State& st) __attribute__((always_inline)) { xana(ex, st, ta, tid); });
             ex.each([&](int, State& st) __attribute__((always_inline)) {
                 NDWT_SFOR(b, 7)                           // the seven detail bands, thresholded where they are
-                    shrink4<T, 1>(st.raw[0][0][b + 1], a.shrink_thr, a.shrink_hard);
+                    shrink4_flat<T>(st.raw[0][0][b + 1], a.shrink_thr, a.shrink_hard);
                 NDWT_SEND
                 st.raw[0][0][0] = st.apx;                 // band 0: the approximation the deeper levels reconstructed
-                if (p + 1 < nplanes) load_apx(st, a, zc0 + p + 1);
+                if (p + 1 < nplanes) load_apx(st, a, za);
             });
+            za = next_plane(za, a.n3);
             ex.each([&](int tid, State& st) __attribute__((always_inline)) { Y::template xsyn<0>(ex, st, sh, tp, p & 1, tid); });
             ex.barrier();
             const int s = p - (L - 1);
@@ -1798,8 +1845,9 @@ template <typename T, int L_, int NT_ = 1024, int WPE_ = 4> struct Den3 {
             if (p + 1 < nplanes) {
                 ex.each([&](int tid, State& st) __attribute__((always_inline)) {
                     zdispatch_a<0>((p + 1) % L, st, sh, ta, tid);
-                    if (p + 2 < nplanes) load_x(st, a, zc0 + p + 2 + ARH);
+                    if (p + 2 < nplanes) load_x(st, a, zx);
                 });
+                zx = next_plane(zx, a.n3);
                 ex.barrier();
             }
         }

@@ -5,7 +5,7 @@
 namespace ndwt {
 
 template <int LL> static int go_den(const Fused3Args<float>& a, const void* taps_dev, hipStream_t s) {
-    typedef Den3<float, LL, 1024, 4> K;
+    typedef Den3<float, LL, 1024, 4, (LL == 8 ? 6 : 0)> K;   // 8 taps: 6 of the 8 pending z sums in LDS (no spills)
     FusedTapsD unused;
     unused.Lp = LL;
     return launch_fused3<K>(a, unused, taps_dev, s);
@@ -21,9 +21,9 @@ int launch_den3_f32(const Fused3Args<float>& a, int Lp, const void* taps_dev, hi
     }
 }
 
-// the tall 64 x 32 tile of the float analysis (Fused3Tile<float, false, 2>), band 0 only
-template <int LL, bool V> static int go_low(const Fused3Args<float>& a, const void* taps_dev, hipStream_t s) {
-    typedef Fused3Tile<float, false, 2> TL;
+// band 0 only: TILE 2 = the tall 64 x 32 tile of the float analysis (1024 threads, one workgroup per CU), 0 = 64 x 16 (256 threads)
+template <int LL, bool V, int TILE = 2> static int go_low(const Fused3Args<float>& a, const void* taps_dev, hipStream_t s) {
+    typedef Fused3Tile<float, false, TILE> TL;
     typedef Fwd3<float, LL, TL::TX, TL::TY, TL::NT, TL::RY, V, TL::WPE, 1, true> K;
     FusedTapsD unused;
     unused.Lp = LL;
@@ -31,6 +31,15 @@ template <int LL, bool V> static int go_low(const Fused3Args<float>& a, const vo
 }
 
 int launch_fwd3_low_f32(const Fused3Args<float>& a, int Lp, bool vec4, const void* taps_dev, hipStream_t s) {
+    if (a.nty == (a.n2 + 15) / 16 && a.nty != (a.n2 + 31) / 32) {     // the caller laid out 64 x 16 tiles
+        switch (Lp) {
+            case 2: return vec4 ? go_low<2, true, 0>(a, taps_dev, s) : go_low<2, false, 0>(a, taps_dev, s);
+            case 4: return vec4 ? go_low<4, true, 0>(a, taps_dev, s) : go_low<4, false, 0>(a, taps_dev, s);
+            case 6: return vec4 ? go_low<6, true, 0>(a, taps_dev, s) : go_low<6, false, 0>(a, taps_dev, s);
+            case 8: return vec4 ? go_low<8, true, 0>(a, taps_dev, s) : go_low<8, false, 0>(a, taps_dev, s);
+            default: return -1;
+        }
+    }
     switch (Lp) {
         case 2: return vec4 ? go_low<2, true>(a, taps_dev, s) : go_low<2, false>(a, taps_dev, s);
         case 4: return vec4 ? go_low<4, true>(a, taps_dev, s) : go_low<4, false>(a, taps_dev, s);

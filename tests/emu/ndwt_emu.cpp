@@ -425,7 +425,7 @@ int emu_yc_small(int depth, int Lp, int vec4, ndwt::Fused3Args<float>& a, const 
 // level 1 of a denoising step in one launch (Den3) and the approximation-only analysis (Fwd3<.., LOWONLY>), production tile
 template <int LL>
 static int run_den3(ndwt::Fused3Args<float>& a, const double* slo, const double* shi, const double* alo, const double* ahi) {
-    typedef ndwt::Den3<float, LL, 1024, 4> K;
+    typedef ndwt::Den3<float, LL, 1024, 4, (LL == 8 ? 6 : 0)> K;
     std::unique_ptr<typename K::Taps> tp(new typename K::Taps);
     for (int ax = 0; ax < 3; ++ax)
         for (int j = 0; j < LL; ++j) {
@@ -443,6 +443,11 @@ static int run_den3(ndwt::Fused3Args<float>& a, const double* slo, const double*
         tp->azp[j][0] = (float)alo[2 * ndwt::kMaxTaps + j];
         tp->azp[j][1] = (float)ahi[2 * ndwt::kMaxTaps + j];
     }
+    for (int k = 0; k <= LL; ++k)
+        for (int h = 0; h < 2; ++h) {
+            const int j = k - h;
+            tp->axp[k][h] = (j >= 0 && j < LL) ? (float)alo[j] : 0.0f;
+        }
     const int nblocks = a.ntx * a.nty * a.nzc * a.nbatch;
     for (int b = 0; b < nblocks; ++b) {
         std::unique_ptr<typename K::Shared> sh(new typename K::Shared);

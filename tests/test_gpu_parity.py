@@ -897,12 +897,14 @@ def test_denoise_with_fused_level1_against_numpy(sizes, wn, level, l2):
     wl = [wn] * 3
     y_ref = orc.spatial_dec(x, wl, level, l2)
     thr = 0.35 * (8.0 ** 0.5 if not l2 else 1.0)
+    w.denoise(xg, level, thr)                                 # (creates the plan)
+    plan = list(w._plans.values())[0]
     for mode in ("soft", "hard"):
+        plan.set_fused_level1(2)                              # 8 taps too (off by default there: not faster)
         got = w.denoise(xg, level, thr, mode)
-        plan = list(w._plans.values())[0]
-        plan.set_fused_level1(False)
+        plan.set_fused_level1(0)
         mat = w.denoise(xg, level, thr, mode)
-        plan.set_fused_level1(True)
+        plan.set_fused_level1(1)
         want = orc.spatial_rec(_np_shrink(y_ref, thr, mode == "hard"), wl, l2)
         scale = max(np.abs(want).max(), 1.0)
         # hard thresholding is discontinuous: coefficients within rounding of the threshold may fall on either side in fp32

@@ -46,9 +46,9 @@ def fused():
 
 
 t_plain, t_three = timed(plain), timed(three_pass)
-plan.set_fused_level1(False)
+plan.set_fused_level1(0)
 t_mat = timed(fused)
-plan.set_fused_level1(True)
+plan.set_fused_level1(2)
 t_fused = timed(fused)
 print(f"{n}^3 {wname} L{level}: dec+rec {t_plain:.3f} ms | dec+shrink+rec {t_three:.3f} ms | ndwt_denoise, level-1 bands in memory {t_mat:.3f} ms | "
       f"ndwt_denoise, level 1 fused {t_fused:.3f} ms")
