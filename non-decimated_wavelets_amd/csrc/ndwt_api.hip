@@ -298,8 +298,9 @@ static bool fused3_eligible(const ndwt_plan* p, long long stride, int* Lp_out, i
     // 18- and 20-tap synthesis exist as the pair-packed kernel only (uniform wavelets, or mixed ones with even padding on every axis)
     if (Lp > lmax && !(dir == 1 && Lp <= 20 && inv3y_plan_ok(p, Lp))) return false;
     if (p->dtype == NDWT_F64 && Lp > 12) return false;   // double: up to db6 (64x8 tiles with 512 threads keep 10 / 12 taps free of spills)
-    // interleaved complex: the fused kernels with the x taps stepping over (re, im) pairs, tap lengths <= 8 (float: <= 12)
-    if (p->complexity != NDWT_REAL && (Lp > (p->dtype == NDWT_F32 ? 12 : 8) || (p->dims[0] * 2) % 4 != 0)) return false;
+    // interleaved complex: the fused kernels with the x taps stepping over (re, im) pairs, tap lengths <= 8 (float: <= 12); rows of an
+    // odd number of elements run the VEC4 = false instances (one access per lane wherever its 4 scalars are contiguous)
+    if (p->complexity != NDWT_REAL && Lp > (p->dtype == NDWT_F32 ? 12 : 8)) return false;
     long long nbatch = p->ndim == 4 ? p->dims[3] + 64 : 1;
     if (!fused3_fits(p->dims[0] * p->comp, p->dims[1], p->dims[2] + 64, nbatch)) return false;
     *Lp_out = Lp;
@@ -339,7 +340,7 @@ static bool fused2_eligible(const ndwt_plan* p, long long stride, int* Lp_out) {
     if (p->path != NDWT_PATH_AUTO || stride != 1 || p->ndim != 2) return false;
     int Lp = p->filt[0].len > p->filt[1].len ? p->filt[0].len : p->filt[1].len;
     if (Lp > 12) return false;
-    if (p->complexity != NDWT_REAL && (Lp > 8 || (p->dims[0] * 2) % 4 != 0)) return false;
+    if (p->complexity != NDWT_REAL && Lp > 8) return false;
     if (p->dims[0] >= (1LL << 30) || p->dims[1] >= (1LL << 30)) return false;
     *Lp_out = Lp;
     return true;

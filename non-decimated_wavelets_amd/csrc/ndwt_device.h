@@ -37,6 +37,12 @@ constexpr int kMaxTaps = 20;
 template <typename T> struct VecT {
     typedef T v2 __attribute__((ext_vector_type(2)));
     typedef T v4 __attribute__((ext_vector_type(4)));
+    // the same vectors at element alignment: global dwordx2 / dwordx4 (x2 for double) accesses need no more than that.  What the
+    // kernels' VEC4 = false instances use for every lane whose 4 x are contiguous in memory -- all but the one lane per row that
+    // straddles the periodic wrap when the row length is not a multiple of 4 (reference shapes: mex/mex_test.m:48,84, 129 x 131 and
+    // 131 x 128 x 30; Test/nddwt1D_test.m:5, N = 54321); that lane, and rows shorter than 4, go element by element.
+    typedef T v2u __attribute__((ext_vector_type(2), aligned(sizeof(T))));
+    typedef T v4u __attribute__((ext_vector_type(4), aligned(sizeof(T))));
 };
 
 NDWT_DEV int modn(int v, int n) {
@@ -244,7 +250,20 @@ struct TileCoord {
     int x0, y0, zbeg, zend, batch;
 };
 
-template <typename T> NDWT_DEV TileCoord decode_tile(const Fused3Args<T>& a, int bid, int TX, int TY) {
+// Tiles of rows that are not whole groups of 4 scalars (the VEC4 = false instances; reference shapes: mex/mex_test.m:48,84,
+// Test/nddwt1D_test.m:5): a lane owns 4 consecutive scalars starting at tile origin + a multiple of 4, and takes them in ONE access
+// when they are contiguous in memory.  With origins at multiples of the tile width the one lane per row whose 4 scalars straddle the
+// periodic wrap goes element by element -- 4 accesses per band in every wave of the last tile column, 2.1x on the whole launch.
+// So the tiles whose haloed extent reaches the end of the row are anchored THERE (origin = n - k * tile width): their lanes are
+// aligned to the wrap point and none straddles it; they overlap the tile before them, whose outputs they write again with the same
+// values.  (Rows shorter than such a tile and its left halo keep the plain origins and the element-wise lane.)
+NDWT_DEV int tile_origin(int t, int ntiles, int width, int n, int halo_l, int halo_r) {
+    const int x0 = t * width;
+    const int xr = n - (ntiles - t) * width;              // origin of tile t counted from the end of the row
+    return (n % 4 != 0 && x0 + width + halo_r > n && xr >= halo_l) ? xr : x0;
+}
+
+template <typename T> NDWT_DEV TileCoord decode_tile(const Fused3Args<T>& a, int bid, int TX, int TY, int halo_l = -1, int halo_r = 0) {
     int nblocks = a.ntx * a.nty * a.nzc * a.nbatch;
     int lb = xcd_remap(bid, nblocks);
     TileCoord tc;
@@ -254,7 +273,7 @@ template <typename T> NDWT_DEV TileCoord decode_tile(const Fused3Args<T>& a, int
     lb /= a.nty;
     int zc = lb % a.nzc;
     tc.batch = lb / a.nzc;
-    tc.x0 = tx * TX;
+    tc.x0 = halo_l >= 0 ? tile_origin(tx, a.ntx, TX, a.n1, halo_l, halo_r) : tx * TX;
     tc.y0 = ty * TY;
     tc.zbeg = zc * a.zchunk;
     tc.zend = tc.zbeg + a.zchunk < a.n3 ? tc.zbeg + a.zchunk : a.n3;
@@ -394,9 +413,13 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
             if constexpr (VEC4) {
                 st.nxt[k] = *reinterpret_cast<const v4*>(p + st.off[k][0]);
             } else {
-                NDWT_SFOR(e, NE)
-                    st.nxt[k][e] = p[st.off[k][e]];
-                NDWT_SEND
+                if (st.off[k][NE - 1] == st.off[k][0] + 3) {          // 4 contiguous x: one access (VecT::v4u)
+                    st.nxt[k] = *reinterpret_cast<const typename VecT<T>::v4u*>(p + st.off[k][0]);
+                } else {
+                    NDWT_SFOR(e, NE)
+                        st.nxt[k][e] = p[st.off[k][e]];
+                    NDWT_SEND
+                }
             }
         NDWT_SEND
     }
@@ -520,6 +543,8 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
                 T* b0 = a.out[0] + off;
                 if constexpr (VEC4) {
                     stream_store(reinterpret_cast<v4*>(b0), o00, a.nt);
+                } else if (gx + 3 < a.n1) {
+                    *reinterpret_cast<typename VecT<T>::v4u*>(b0) = o00;
                 } else {
                     NDWT_UNROLL
                     for (int e = 0; e < 4; ++e)
@@ -536,6 +561,12 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
                 stream_store(reinterpret_cast<v4*>(b10), o10, a.nt);
                 stream_store(reinterpret_cast<v4*>(b01), o01, a.nt);
                 stream_store(reinterpret_cast<v4*>(b11), o11, a.nt);
+            } else if (gx + 3 < a.n1) {
+                typedef typename VecT<T>::v4u v4u;
+                *reinterpret_cast<v4u*>(b00) = o00;
+                *reinterpret_cast<v4u*>(b10) = o10;
+                *reinterpret_cast<v4u*>(b01) = o01;
+                *reinterpret_cast<v4u*>(b11) = o11;
             } else {
                 NDWT_UNROLL
                 for (int e = 0; e < 4; ++e) {
@@ -546,7 +577,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
     }
 
     template <class Exec> static NDWT_DEV void block(Exec& ex, Shared& sh, const Args& a, const Taps& tp, int bid) {
-        const TileCoord tc = decode_tile(a, bid, TX, TY);
+        const TileCoord tc = decode_tile(a, bid, TX, TY, VEC4 ? -1 : 4 * GL, 4 * GR);
         const T* inb = a.in[0] + batch_base(tc.batch, a.bsplit, a.in_bstride, a.in_bstride2);
         const long long obase = batch_base(tc.batch, a.bsplit, a.out_bstride, a.out_bstride2);
         // planes zbeg-LH .. zbeg-LH+L-2 into slots 0..L-2, then prefetch the plane of step 0
@@ -762,7 +793,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
     }
 
     template <class Exec> static NDWT_DEV void block(Exec& ex, Shared& sh, const Args& a, const Taps& tp, int bid) {
-        const TileCoord tc = decode_tile(a, bid, TX, TY);
+        const TileCoord tc = decode_tile(a, bid, TX, TY, VEC4 ? -1 : 4 * GL, 4 * GR);
         const long long ibase = batch_base(tc.batch, a.bsplit, a.in_bstride, a.in_bstride2);
         const long long obase = batch_base(tc.batch, a.bsplit, a.out_bstride, a.out_bstride2);
         const int zsh = tc.batch * a.zbs;
@@ -911,17 +942,24 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
         NDWT_SFOR(k, NRND)
             // lanes (and whole waves) without a row issue no loads: the per-CU vector-memory pipe bounds these kernels, and the
             // waves past the last haloed row used to re-load a clamped row (3 of 16 waves on the 64x32 tile)
-            if (st.off[k][0] >= 0) {
-                NDWT_SFOR(b, 8)
-                    const T* p = a.in[b] + pb;
-                    if constexpr (VEC4) {
-                        st.raw[k][b] = *reinterpret_cast<const v4*>(p + st.off[k][0]);
-                    } else {
+            if constexpr (VEC4) {
+                if (st.off[k][0] >= 0) {
+                    NDWT_SFOR(b, 8)
+                        st.raw[k][b] = *reinterpret_cast<const v4*>(a.in[b] + pb + st.off[k][0]);
+                    NDWT_SEND
+                }
+            } else {
+                if (st.off[k][0] >= 0 && st.off[k][NE - 1] == st.off[k][0] + 3) {      // 4 contiguous x: one access per band (VecT::v4u)
+                    NDWT_SFOR(b, 8)
+                        st.raw[k][b] = *reinterpret_cast<const typename VecT<T>::v4u*>(a.in[b] + pb + st.off[k][0]);
+                    NDWT_SEND
+                } else if (st.off[k][0] >= 0) {
+                    NDWT_SFOR(b, 8)
                         NDWT_SFOR(e, NE)
-                            st.raw[k][b][e] = p[st.off[k][e]];
+                            st.raw[k][b][e] = (a.in[b] + pb)[st.off[k][e]];
                         NDWT_SEND
-                    }
-                NDWT_SEND
+                    NDWT_SEND
+                }
             }
         NDWT_SEND
     }
@@ -1042,6 +1080,8 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
                             T* dst = a.out[0] + obase + (long long)z * a.plane + (long long)gy * a.rs + gx;
                             if constexpr (VEC4 && CH == 2) {
                                 if (gx < a.n1) stream_store(reinterpret_cast<v2*>(dst), v2{st.zacc[k][done][i * CH], st.zacc[k][done][i * CH + CH - 1]}, a.nt);
+                            } else if (CH == 2 && gx + 1 < a.n1) {
+                                *reinterpret_cast<typename VecT<T>::v2u*>(dst) = v2{st.zacc[k][done][i * CH], st.zacc[k][done][i * CH + CH - 1]};
                             } else {
                                 NDWT_SFOR(sub, CH)
                                     if (gx + sub < a.n1) dst[sub] = st.zacc[k][done][i * CH + sub];
@@ -1063,7 +1103,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
     }
 
     template <class Exec> static NDWT_DEV void block(Exec& ex, Shared& sh, const Args& a, const Taps& tp, int bid) {
-        const TileCoord tc = decode_tile(a, bid, TX, TY);
+        const TileCoord tc = decode_tile(a, bid, TX, TY, VEC4 ? -1 : 4 * GL, 4 * GR);
         const long long ibase = batch_base(tc.batch, a.bsplit, a.in_bstride, a.in_bstride2);
         const long long obase = batch_base(tc.batch, a.bsplit, a.out_bstride, a.out_bstride2);
         const int zsh = tc.batch * a.zbs;
@@ -1244,8 +1284,9 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
         *reinterpret_cast<__attribute__((address_space(1))) V*>((gptr)uniform_bits(base) + off) = v;
     }
 #else
-    template <class V> static NDWT_DEV V gload(const void* base, unsigned off) { return *reinterpret_cast<const V*>((const char*)base + off); }
-    template <class V> static NDWT_DEV void gstore(void* base, unsigned off, V v, int) { *reinterpret_cast<V*>((char*)base + off) = v; }
+    // (memcpy: a template argument drops the element alignment of VecT::v4u / v2u, and the host would use aligned vector moves)
+    template <class V> static NDWT_DEV V gload(const void* base, unsigned off) { V v; __builtin_memcpy(&v, (const char*)base + off, sizeof(V)); return v; }
+    template <class V> static NDWT_DEV void gstore(void* base, unsigned off, V v, int) { __builtin_memcpy((char*)base + off, &v, sizeof(V)); }
 #endif
 
     // ---- packed FMAs with explicit operand selection (v_pk_fma_f32 op_sel / neg modifiers) ----
@@ -1352,17 +1393,26 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
         }
         const long long pb = ibase + zm * a.plane;
         NDWT_SFOR(k, NRND)
-            if (st.off[k][0] != kNoRow) {
-                NDWT_SFOR(b, 8)
-                    const T* p = a.in[b] + pb;           // wave-uniform
-                    if constexpr (VEC4) {
-                        st.raw[SET][k][b] = gload<v4>(p, st.off[k][0]);
-                    } else {
+            if constexpr (VEC4) {
+                if (st.off[k][0] != kNoRow) {
+                    NDWT_SFOR(b, 8)
+                        st.raw[SET][k][b] = gload<v4>(a.in[b] + pb, st.off[k][0]);          // (a.in[b] + pb: wave-uniform)
+                    NDWT_SEND
+                }
+            } else {
+                // rows that are not whole groups of 4: every lane whose 4 x are contiguous in memory still takes them in one access
+                // (VecT::v4u); the one lane per row that straddles the periodic wrap (and rows shorter than 4) go element by element
+                if (st.off[k][0] != kNoRow && st.off[k][NE - 1] == st.off[k][0] + 3 * (unsigned)sizeof(T)) {
+                    NDWT_SFOR(b, 8)
+                        st.raw[SET][k][b] = gload<typename VecT<T>::v4u>(a.in[b] + pb, st.off[k][0]);
+                    NDWT_SEND
+                } else if (st.off[k][0] != kNoRow) {
+                    NDWT_SFOR(b, 8)
                         NDWT_SFOR(e, NE)
-                            st.raw[SET][k][b][e] = gload<T>(p, st.off[k][e]);
+                            st.raw[SET][k][b][e] = gload<T>(a.in[b] + pb, st.off[k][e]);
                         NDWT_SEND
-                    }
-                NDWT_SEND
+                    NDWT_SEND
+                }
             }
         NDWT_SEND
     }
@@ -1488,9 +1538,10 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
                     T* dst = a.out[0] + obase + (long long)z * a.plane;   // wave-uniform
                     if constexpr (VEC4) {
                         gstore<v2>(dst, st.ooff[k], o, a.nt);
+                    } else if (st.ostore[k] == 2) {
+                        gstore<typename VecT<T>::v2u>(dst, st.ooff[k], o, 0);
                     } else {
                         gstore<T>(dst, st.ooff[k], o.x, 0);
-                        if (st.ostore[k] == 2) gstore<T>(dst, st.ooff[k] + (unsigned)sizeof(T), o.y, 0);
                     }
                 }
             }
@@ -1516,7 +1567,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
     template <class Exec> static NDWT_DEV void block(Exec& ex, Shared& sh, const Args& a, const Taps& tpm, int bid) {
         RegTaps tp;
         load_taps(tp, tpm);
-        const TileCoord tc = decode_tile(a, bid, TX, TY);
+        const TileCoord tc = decode_tile(a, bid, TX, TY, VEC4 ? -1 : 4 * (GL + XH), 4 * (GR + XH));
         const long long ibase = batch_base(tc.batch, a.bsplit, a.in_bstride, a.in_bstride2);
         const long long obase = batch_base(tc.batch, a.bsplit, a.out_bstride, a.out_bstride2);
         const int zsh = tc.batch * a.zbs;
@@ -1878,13 +1929,13 @@ template <typename T> struct Fused2Args {
 struct Tile2Coord {
     int x0, ybeg, yend, batch;
 };
-template <typename T> NDWT_DEV Tile2Coord decode_tile2(const Fused2Args<T>& a, int bid, int WX) {
+template <typename T> NDWT_DEV Tile2Coord decode_tile2(const Fused2Args<T>& a, int bid, int WX, int halo_l = -1, int halo_r = 0) {
     Tile2Coord tc;
     int tx = bid % a.ntx;
     bid /= a.ntx;
     int yc = bid % a.nyc;
     tc.batch = bid / a.nyc;
-    tc.x0 = tx * WX;
+    tc.x0 = halo_l >= 0 ? tile_origin(tx, a.ntx, WX, a.n1, halo_l, halo_r) : tx * WX;
     tc.ybeg = yc * a.ychunk;
     tc.yend = tc.ybeg + a.ychunk < a.n2 ? tc.ybeg + a.ychunk : a.n2;
     return tc;
@@ -1921,6 +1972,8 @@ template <typename T, int L_, bool VEC4_, int WPE_ = 4, int EW_ = 1> struct Fwd2
         const T* p = inb + ym * a.rs;
         if constexpr (VEC4) {
             st.nxt = *reinterpret_cast<const v4*>(p + st.off[0]);
+        } else if (st.off[NE - 1] == st.off[0] + 3) {           // 4 contiguous x: one access (VecT::v4u)
+            st.nxt = *reinterpret_cast<const typename VecT<T>::v4u*>(p + st.off[0]);
         } else {
             NDWT_SFOR(e, NE)
                 st.nxt[e] = p[st.off[e]];
@@ -1985,6 +2038,12 @@ template <typename T, int L_, bool VEC4_, int WPE_ = 4, int EW_ = 1> struct Fwd2
             stream_store(reinterpret_cast<v4*>(a.out[1] + off), o1, a.nt);
             stream_store(reinterpret_cast<v4*>(a.out[2] + off), o2, a.nt);
             stream_store(reinterpret_cast<v4*>(a.out[3] + off), o3, a.nt);
+        } else if (gx + 3 < a.n1) {
+            typedef typename VecT<T>::v4u v4u;
+            *reinterpret_cast<v4u*>(a.out[0] + off) = o0;
+            *reinterpret_cast<v4u*>(a.out[1] + off) = o1;
+            *reinterpret_cast<v4u*>(a.out[2] + off) = o2;
+            *reinterpret_cast<v4u*>(a.out[3] + off) = o3;
         } else {
             NDWT_SFOR(e, 4)
                 if (gx + e < a.n1) { a.out[0][off + e] = o0[e]; a.out[1][off + e] = o1[e]; a.out[2][off + e] = o2[e]; a.out[3][off + e] = o3[e]; }
@@ -1993,7 +2052,7 @@ template <typename T, int L_, bool VEC4_, int WPE_ = 4, int EW_ = 1> struct Fwd2
     }
 
     template <class Exec> static NDWT_DEV void block(Exec& ex, Shared&, const Args& a, const Taps& tp, int bid) {
-        const Tile2Coord tc = decode_tile2(a, bid, WX);
+        const Tile2Coord tc = decode_tile2(a, bid, WX, VEC4 ? -1 : 4 * GL, 4 * GR);
         const T* inb = a.in[0] + (long long)tc.batch * a.in_bstride;
         const long long obase = (long long)tc.batch * a.out_bstride;
         ex.each([&](int tid, State& st) __attribute__((always_inline)) {
@@ -2039,16 +2098,21 @@ template <typename T, int L_, bool VEC4_, int WPE_ = 4, int EW_ = 1> struct Inv2
     }
     static NDWT_DEV void load_row(State& st, const Args& a, long long ibase, int yraw) {
         long long ym = a.y_wrap ? (long long)modn(yraw, a.n2) : (long long)(yraw + LH);
-        NDWT_SFOR(b, 4)
-            const T* p = a.in[b] + ibase + ym * a.rs;
-            if constexpr (VEC4) {
-                st.raw[b] = *reinterpret_cast<const v4*>(p + st.off[0]);
-            } else {
+        if constexpr (VEC4) {
+            NDWT_SFOR(b, 4)
+                st.raw[b] = *reinterpret_cast<const v4*>(a.in[b] + ibase + ym * a.rs + st.off[0]);
+            NDWT_SEND
+        } else if (st.off[NE - 1] == st.off[0] + 3) {           // 4 contiguous x: one access per band (VecT::v4u)
+            NDWT_SFOR(b, 4)
+                st.raw[b] = *reinterpret_cast<const typename VecT<T>::v4u*>(a.in[b] + ibase + ym * a.rs + st.off[0]);
+            NDWT_SEND
+        } else {
+            NDWT_SFOR(b, 4)
                 NDWT_SFOR(e, NE)
-                    st.raw[b][e] = p[st.off[e]];
+                    st.raw[b][e] = (a.in[b] + ibase + ym * a.rs)[st.off[e]];
                 NDWT_SEND
-            }
-        NDWT_SEND
+            NDWT_SEND
+        }
     }
     // x-synthesis of the newest row via lane shifts, then y-synthesis (scatter); rotation R as in Inv3S
     template <int R, class Exec>
@@ -2096,6 +2160,8 @@ template <typename T, int L_, bool VEC4_, int WPE_ = 4, int EW_ = 1> struct Inv2
         long long off = obase + (long long)y * a.rs + gx;
         if constexpr (VEC4) {
             stream_store(reinterpret_cast<v4*>(a.out[0] + off), v4{st.yacc[done][0], st.yacc[done][1], st.yacc[done][2], st.yacc[done][3]}, a.nt);
+        } else if (gx + 3 < a.n1) {
+            *reinterpret_cast<typename VecT<T>::v4u*>(a.out[0] + off) = v4{st.yacc[done][0], st.yacc[done][1], st.yacc[done][2], st.yacc[done][3]};
         } else {
             NDWT_SFOR(e, 4)
                 if (gx + e < a.n1) a.out[0][off + e] = st.yacc[done][e];
@@ -2111,7 +2177,7 @@ template <typename T, int L_, bool VEC4_, int WPE_ = 4, int EW_ = 1> struct Inv2
         }
     }
     template <class Exec> static NDWT_DEV void block(Exec& ex, Shared&, const Args& a, const Taps& tp, int bid) {
-        const Tile2Coord tc = decode_tile2(a, bid, WX);
+        const Tile2Coord tc = decode_tile2(a, bid, WX, VEC4 ? -1 : 4 * GL, 4 * GR);
         const long long ibase = (long long)tc.batch * a.in_bstride;
         const long long obase = (long long)tc.batch * a.out_bstride;
         const int nsteps = tc.yend - tc.ybeg;
@@ -2283,6 +2349,8 @@ template <typename T, int L_, bool SYN, int EW_, bool VEC4_> struct AxisX {
             const T* p = (b == 0 ? a.in0 : a.in1) + st.ibase;
             if constexpr (VEC4) {
                 st.raw[b] = *reinterpret_cast<const v4*>(p + modn64(st.xg, a.row));
+            } else if (st.xg >= 0 && (long long)st.xg + 3 < a.row) {      // 4 contiguous scalars: one access (VecT::v4u)
+                st.raw[b] = *reinterpret_cast<const typename VecT<T>::v4u*>(p + st.xg);
             } else {
                 NDWT_SFOR(e, 4)
                     st.raw[b][e] = p[modn64((long long)st.xg + e, a.row)];
@@ -2312,6 +2380,9 @@ template <typename T, int L_, bool SYN, int EW_, bool VEC4_> struct AxisX {
         if constexpr (VEC4) {
             *reinterpret_cast<v4*>(a.out0 + st.obase + st.xg) = o0;
             if constexpr (!SYN) *reinterpret_cast<v4*>(a.out1 + st.obase + st.xg) = o1;
+        } else if ((long long)st.xg + 3 < a.row) {
+            *reinterpret_cast<typename VecT<T>::v4u*>(a.out0 + st.obase + st.xg) = o0;
+            if constexpr (!SYN) *reinterpret_cast<typename VecT<T>::v4u*>(a.out1 + st.obase + st.xg) = o1;
         } else {
             NDWT_SFOR(e, 4)
                 if (st.xg + e < a.row) {
@@ -2330,7 +2401,9 @@ template <typename T, int L_, bool SYN, int EW_, bool VEC4_> struct AxisX {
             const long long o = it / a.nseg, sg = it % a.nseg;
             st.ibase = o * a.row;
             st.obase = o * a.row;
-            st.xg = (int)(sg * WX) + 4 * (tid % 64 - GL);
+            // (row segments like tiles: the ones that reach the end of a row whose length is not a multiple of 4 are anchored there)
+            const int seg0 = (VEC4 || a.row >= (1LL << 30)) ? (int)(sg * WX) : tile_origin((int)sg, (int)a.nseg, WX, (int)a.row, 4 * GL, 4 * GR);
+            st.xg = seg0 + 4 * (tid % 64 - GL);
             load(st, a);
         });
         ex.each([&](int tid, State& st) __attribute__((always_inline)) { compute(ex, st, a, tp, tid); });

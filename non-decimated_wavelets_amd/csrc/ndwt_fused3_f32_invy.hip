@@ -13,26 +13,31 @@ template <int LL, bool V, int DEPTH> static int go(const Fused3Args<float>& a, c
 // workgroup without spills: tap lengths 2, 8 and 10 as they are; 12 with 6 of the pending z sums in LDS
 // (inv3y_zlds; 4 and 6 taps fit that way too and run slower than depth 1; a spill reload in the plane loop would wait vmcnt(0), i.e. for every load in flight); depth 1 serves the longer
 // filters, unaligned volumes and A/B runs
-#define NDWT_INVY_CASE(LL, D2OK) \
+// D2RAG: depth 2 also for rows that are not whole groups of 4 scalars (the VEC4 = false instance keeps 4 offsets per lane: 2 and 8
+// taps fit, 10 and 12 would spill)
+#define NDWT_INVY_CASE(LL, D2OK, D2RAG) \
     case LL:                     \
         if constexpr (D2OK) {    \
             if (vec4 && depth == 2) return go<LL, true, 2>(a, taps_dev, s); \
+        }                        \
+        if constexpr (D2RAG) {   \
+            if (!vec4 && depth == 2) return go<LL, false, 2>(a, taps_dev, s); \
         }                        \
         return vec4 ? go<LL, true, 1>(a, taps_dev, s) : go<LL, false, 1>(a, taps_dev, s);
 
 int launch_inv3y_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, const void* taps_dev, hipStream_t s) {
     switch (Lp) {
-        NDWT_INVY_CASE(8, true)
+        NDWT_INVY_CASE(8, true, true)
 #ifndef NDWT_INVY_DB4_ONLY
-        NDWT_INVY_CASE(2, true)
-        NDWT_INVY_CASE(4, false)
-        NDWT_INVY_CASE(6, false)
-        NDWT_INVY_CASE(10, true)
-        NDWT_INVY_CASE(12, true)
-        NDWT_INVY_CASE(14, false)
-        NDWT_INVY_CASE(16, false)
-        NDWT_INVY_CASE(18, false)     // 64 x 24 tile: 41 haloed rows on 14 waves
-        NDWT_INVY_CASE(20, false)     // 48 x 28 tile: 47 haloed rows on 16 waves (3 spilled registers, reloaded once per plane)
+        NDWT_INVY_CASE(2, true, true)
+        NDWT_INVY_CASE(4, false, false)
+        NDWT_INVY_CASE(6, false, false)
+        NDWT_INVY_CASE(10, true, false)
+        NDWT_INVY_CASE(12, true, false)
+        NDWT_INVY_CASE(14, false, false)
+        NDWT_INVY_CASE(16, false, false)
+        NDWT_INVY_CASE(18, false, false)     // 64 x 24 tile: 41 haloed rows on 14 waves
+        NDWT_INVY_CASE(20, false, false)     // 48 x 28 tile: 47 haloed rows on 16 waves (3 spilled registers, reloaded once per plane)
 #endif
         default: return -1;
     }

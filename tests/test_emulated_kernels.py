@@ -64,6 +64,8 @@ CASES = [
     ((20, 17, 12), ("db4", "db4", "db4"), True, 5, True),
     ((68, 18, 9), ("db4", "db4", "db4"), True, 0, False),       # production tile shape (db4 only)
     ((70, 19, 10), ("db2", "db1", "db4"), False, 6, False),
+    ((134, 20, 7), ("db4", "db4", "db4"), False, 0, False),      # three production tiles along x, the last anchored at the end of the row
+    ((130, 18, 6), ("db4", "db4", "db4"), False, 0, False),      # a 2-column last tile; the tile before it reaches past the end too
 ]
 
 
@@ -108,6 +110,8 @@ CASES_Y = [
     ((24, 19, 11), ("db6", "db2", "db4"), True, 0, True),        # two-hop lane shifts
     ((68, 39, 9), ("db4", "db4", "db4"), True, 0, False),        # production tile shape (8 and 12 taps): ragged in x and y
     ((70, 60, 10), ("db2", "db2", "db4"), False, 6, False),
+    ((134, 36, 7), ("db4", "db4", "db4"), False, 0, False),      # ragged rows on the production tile: end tiles anchored at the row end
+    ((131, 34, 6), ("db6", "db6", "db6"), False, 0, False),
     ((24, 21, 13), ("db5", "db5", "db5"), True, 0, True),
     ((21, 14, 12), ("db5", "db3", "db1"), False, 5, True),
     ((24, 23, 19), ("db7", "db7", "db7"), True, 0, True),
@@ -143,6 +147,7 @@ CASES_YC = [
     ((18, 13, 11), ("db5", "db3", "db1"), True, 0),
     ((20, 15, 13), ("db6", "db6", "db6"), True, 6),              # 6 halo groups of two elements each
     ((13, 12, 12), ("db6", "db2", "db4"), False, 0),
+    ((67, 35, 8), ("db4", "db4", "db4"), False, 0),              # 134 scalars per row: the last lane of a row straddles the wrap
 ]
 
 
@@ -196,6 +201,8 @@ CASES2 = [
     ((516, 20), ("db4", "db4"), True, 7),      # three wave tiles, several row chunks
     ((36, 30), ("db6", "db5"), True, 11),      # two-lane shifts
     ((30, 12), ("db2", "db6"), False, 0),
+    ((301, 9), ("db4", "db4"), False, 0),      # two wave tiles, the second anchored at the end of the row (ndwt_device.h: tile_origin)
+    ((250, 8), ("db3", "db4"), False, 3),      # a second tile of 2 columns that cannot be anchored (the row is shorter than a tile + halo)
 ]
 
 
@@ -266,6 +273,8 @@ AXISX = [
     ((2, 37), "db4", False, False),       # odd length: scalar loads/stores
     ((3, 50), "db4", True, True),         # interleaved complex: taps step over (re, im) pairs, two-lane shifts
     ((1, 131), "db6", True, False),
+    ((2, 541), "db4", False, False),      # three wave segments, the last anchored at the end of the row
+    ((1, 277), "db1", True, False),
     ((2, 64), "db6", False, True),
 ]
 

@@ -104,6 +104,39 @@ def test_reference_test_scripts(d, sizes, wname, level, l2, precision):
     assert err < (1e-6 if precision == "single" else 1e-13)                                    # (A)
 
 
+# the shapes of the reference's cross-backend scripts (mex/mex_test.m:11,48,84,120: 1-D n = 10000; 2-D 129 x 131; 3-D 131 x 128 x 30;
+# 4-D 128 x 68 x 8 x 8 db3; complex randn input) and of Test/nddwt1D_test.m:5 -- rows that are not whole groups of 4 scalars
+MEX_TESTS = [
+    (1, [10000], "db1", 3, None),
+    (1, [54321], "db2", 4, None),
+    (2, [129, 131], "db1", 2, "fused2d"),
+    (2, [129, 131], "db4", 2, "fused2d"),
+    (3, [131, 128, 30], "db1", 2, "fused3d"),
+    (3, [131, 128, 30], "db3", 2, "fused3d"),
+    (4, [128, 68, 8, 8], "db3", 1, "axis+fused3d"),
+]
+
+
+@pytest.mark.parametrize("d,sizes,wname,level,path", MEX_TESTS)
+@pytest.mark.parametrize("precision,cplx", [("double", True), ("single", True), ("single", False)])
+def test_reference_mex_test_shapes(d, sizes, wname, level, path, precision, cplx):
+    """odd row lengths (complex: an odd number of elements) run the fused kernels' VEC4 = false instances -- one access per lane
+    wherever its 4 scalars are contiguous, end-of-row tiles anchored at the row end -- and agree with the oracle like any other shape"""
+    rng = np.random.default_rng(60 + d)
+    x = rng.standard_normal(sizes) + (1j * rng.standard_normal(sizes) if cplx else 0)
+    w = _cls(d)(wname, sizes[0] if d == 1 else sizes, "pres_l2_norm", 1, "precision", precision)
+    xg = _colmajor_gpu(x, precision)
+    y = w.dec(xg, level)
+    if path is not None:
+        assert list(w._plans.values())[0].describe() == path
+    want = orc.NdDwtMat(wname, sizes, 1).dec(x, level)
+    assert _relerr(y.cpu().numpy(), want) <= TOL[precision]
+    c = rng.standard_normal(want.shape) + (1j * rng.standard_normal(want.shape) if cplx else 0)     # rec of arbitrary coefficients
+    r = w.rec(_colmajor_gpu(c, precision))
+    want_r = orc.NdDwtMat(wname, sizes, 1).rec(c)
+    assert _relerr(r.cpu().numpy(), want_r) <= 4 * TOL[precision]
+
+
 RANDOM = [
     # d, sizes, wavelets, level
     (1, [97], "db5", 3),
