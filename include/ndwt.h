@@ -159,6 +159,9 @@ int ndwt_rec_split_host(ndwt_plan* plan, const void* y_re, const void* y_im, voi
  * length L; the 2^d outputs are local-sized.  Synthesis: every one of the 2^d inputs holds
  * halo_before = (L/2)*stride and halo_after = (L/2-1)*stride planes around the local slab.
  * ndwt_slab_halo() reports those four numbers. */
+/* 1 when the plan offers the slab forms that read a slab in place (split-halo analysis, runs of the zero-extended synthesis:
+ * a 3-D plan on the fused kernels whose outer-axis filter is its longest), else 0 */
+int ndwt_plan_slab_fast(const ndwt_plan* plan);
 int ndwt_slab_halo(const ndwt_plan* plan, int stride, int64_t* ana_before, int64_t* ana_after,
                    int64_t* syn_before, int64_t* syn_after);
 int ndwt_analysis_level_slab(ndwt_plan* plan, const void* in_with_halo, void* const* out_bands, int stride, void* stream);
@@ -196,16 +199,29 @@ int ndwt_synthesis_level_slab_runs(ndwt_plan* plan, const void* const* in_local,
 /* ---- single-process multi-device plan (hard part 5; section 8b `devices[]`) ---------------------------
  * The reference's host is ONE process calling one gateway (nd_dwt_3D.m:161,225): this is the multi-GPU path that fits behind
  * that call.  The volume is sharded in slabs on its outermost axis over devices[0..ndev) (a device may appear more than once:
- * independent slabs and streams on one GPU); one host thread drives all of them, halo planes move between slabs with
- * asynchronous device-to-device (peer, xGMI) copies ordered by events.  Host arrays in and out, whole volume, the layout of
- * ndwt_dec_host / ndwt_rec_host; results equal the single-device transform bit for bit (gather exchange in both directions).
- * ndim 2..4.  Errors: ndwt_mplan_last_error(). */
+ * independent slabs and streams on one GPU); one host thread drives all of them, planes move between slabs with asynchronous
+ * device-to-device (peer, xGMI) copies ordered by events.  ndim 2..4.  Errors: ndwt_mplan_last_error().
+ *   ndwt_mdec / ndwt_mrec: DEVICE-RESIDENT data, one pointer per slab (ndwt_mplan_slab gives its device and planes): x_slabs[i] =
+ *     the n_i planes of the signal on slab i's device, y_slabs[i] = its coefficient slab, band b at b * n_i planes.  The kernels
+ *     read and write these buffers in place.  The data must be complete when the call is made; the call returns when the result is.
+ *   ndwt_mdec_host / ndwt_mrec_host: whole-volume host arrays (the layout of ndwt_dec_host / ndwt_rec_host), staged through
+ *     slab buffers of the plan.
+ *   Exchange per level: analysis -- halo planes of the approximation band (bit-identical to one device).  Synthesis --
+ *     NDWT_EXCHANGE_SCATTER (default where every level runs the fused 3-D kernels): each slab reconstructs its own coefficients
+ *     zero-extended and sends ONE band of partial sums for the L-1 planes around it, which their owners add in a fixed order
+ *     (equal to one device to rounding); NDWT_EXCHANGE_GATHER: halo planes of all 2^d bands assembled with a copy of the slab
+ *     (bit-identical to one device; what plans on the per-axis kernels, dilated levels, 2-D and 4-D plans use anyway). */
 typedef struct ndwt_mplan ndwt_mplan;
+enum { NDWT_EXCHANGE_SCATTER = 0, NDWT_EXCHANGE_GATHER = 1 };
 int ndwt_mplan_create(ndwt_mplan** plan, int ndim, const int64_t* dims, const char* const* wnames, int dtype, int complexity,
                       int pres_l2_norm, int dilation, int max_level, const int* devices, int ndev);
 int ndwt_mplan_destroy(ndwt_mplan* plan);
 int ndwt_mplan_num_slabs(const ndwt_mplan* plan);
 int ndwt_mplan_slab(const ndwt_mplan* plan, int idx, int* device, int64_t* first_plane, int64_t* planes);
+int ndwt_mplan_set_exchange(ndwt_mplan* plan, int exchange);
+int ndwt_mplan_describe(const ndwt_mplan* plan, char* buf, int buflen);   /* slabs, exchange schemes, peer-access findings */
+int ndwt_mdec(ndwt_mplan* plan, const void* const* x_slabs, void* const* y_slabs, int level);
+int ndwt_mrec(ndwt_mplan* plan, const void* const* y_slabs, void* const* x_slabs, int level);
 int ndwt_mdec_host(ndwt_mplan* plan, const void* x_host, void* y_host, int level);
 int ndwt_mrec_host(ndwt_mplan* plan, const void* y_host, void* x_host, int level);
 const char* ndwt_mplan_last_error(void);

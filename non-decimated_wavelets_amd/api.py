@@ -238,6 +238,48 @@ class MultiPlan:
         L.mcheck(L.lib().ndwt_mrec_host(self._h, y.ctypes.data_as(ctypes.c_void_p), x.ctypes.data_as(ctypes.c_void_p), level))
         return x
 
+    def set_exchange(self, scheme):
+        """'scatter' (default: one band of partial sums per level; equal to one device to rounding) or 'gather' (bit-identical)"""
+        L.mcheck(L.lib().ndwt_mplan_set_exchange(self._h, {"scatter": 0, "gather": 1}[scheme]))
+        return self
+
+    def describe(self) -> str:
+        buf = ctypes.create_string_buffer(512)
+        L.mcheck(L.lib().ndwt_mplan_describe(self._h, buf, 512))
+        return buf.value.decode()
+
+    def _slab_tensors(self, tensors, bands):
+        sl = self.slabs()
+        tdt = {np.float32: torch.float32, np.float64: torch.float64}[self.np_dtype]
+        if self.complex:
+            tdt = {torch.float32: torch.complex64, torch.float64: torch.complex128}[tdt]
+        if len(tensors) != len(sl):
+            raise ValueError(f"{len(sl)} slab tensors expected")
+        for t, (dev, _, n) in zip(tensors, sl):
+            shape = ((bands,) if bands else ()) + (n,) + tuple(reversed(self.dims[:-1]))
+            if not (t.is_cuda and t.device.index == dev and t.dtype == tdt and t.is_contiguous() and tuple(t.shape) == shape):
+                raise ValueError(f"slab tensor: contiguous {tdt} of shape {shape} on cuda:{dev} expected")
+        return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+    def dec_device(self, x_slabs, level):
+        """device-resident form: x_slabs[i] = torch tensor (n_i, ..., n1) on slab i's device -> list of (bands, n_i, ..., n1) tensors.
+        The inputs must be complete (synchronise the streams that produced them); returns when the result is."""
+        xs = self._slab_tensors(x_slabs, 0)
+        nbt = num_bands(self.ndim, level)
+        ys = [torch.empty((nbt,) + tuple(t.shape), dtype=t.dtype, device=t.device) for t in x_slabs]
+        L.mcheck(L.lib().ndwt_mdec(self._h, xs, self._slab_tensors(ys, nbt), int(level)))
+        return ys
+
+    def rec_device(self, y_slabs):
+        nbt = int(y_slabs[0].shape[0])
+        level = L.lib().ndwt_level_from_bands(self.ndim, nbt)
+        if level < 1:
+            raise ValueError(f"{nbt} bands is not a valid {self.ndim}-D coefficient count")
+        ys = self._slab_tensors(y_slabs, nbt)
+        xs = [torch.empty(tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in y_slabs]
+        L.mcheck(L.lib().ndwt_mrec(self._h, ys, self._slab_tensors(xs, 0), level))
+        return xs
+
 
 def num_bands(ndim, level):
     return int(L.lib().ndwt_num_bands(int(ndim), int(level)))
@@ -340,15 +382,24 @@ class _NdDwtBase:
         return torch.device("cuda", torch.cuda.current_device())
 
     def _plan(self, is_complex, level, dev):
-        # one plan per (data kind, device, stream): a plan owns scratch and serves one stream at a time (include/ndwt.h)
+        # ONE plan per (data kind, device): a plan owns scratch (GBs for large volumes) and serves one stream at a time
+        # (include/ndwt.h).  A call on another torch stream than the plan's previous one first makes the new stream wait for
+        # everything queued on the old one, so the scratch is never shared by two streams in flight and nothing accumulates per stream.
         idx = dev.index if dev.index is not None else torch.cuda.current_device()
-        key = (is_complex, idx, _current_stream(dev))
+        key = (is_complex, idx)
         p = self._plans.get(key)
         if p is None or p.max_level < level:
             real_dt = torch.float32 if self.precision.lower() == "single" else torch.float64
+            if p is not None:
+                torch.cuda.synchronize(idx)                           # the plan being replaced may still be running
             p = Plan(self.sizes, self.wname[: self.NDIM], real_dt, is_complex, self.pres_l2_norm, self.dilation,
                      max_level=max(level, 3), device=idx)
+            p._last_stream = None
             self._plans[key] = p
+        cur = torch.cuda.current_stream(torch.device("cuda", idx))
+        if p._last_stream is not None and p._last_stream != cur:
+            cur.wait_event(p._last_stream.record_event())
+        p._last_stream = cur
         return p
 
     def _to_device_kernel_order(self, x, dev, ndim_expected):

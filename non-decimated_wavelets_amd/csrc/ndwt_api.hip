@@ -1435,6 +1435,11 @@ int ndwt_rec_split_host(ndwt_plan* p, const void* y_re, const void* y_im, void* 
     return rc;
 }
 
+int ndwt_plan_slab_fast(const ndwt_plan* p) {
+    int Lp = 0;
+    return p && p->ndim == 3 && fused3_eligible(p, 1, &Lp) && p->filt[2].len == Lp ? 1 : 0;
+}
+
 int ndwt_slab_halo(const ndwt_plan* p, int stride, int64_t* ab, int64_t* aa, int64_t* sb, int64_t* sa) {
     if (!p || stride < 1) return fail(NDWT_ERR_INVALID_ARG, "bad plan/stride");
     const int L = p->filt[p->ndim - 1].len;

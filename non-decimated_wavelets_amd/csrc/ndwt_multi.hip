@@ -3,14 +3,23 @@
 // The reference's host is one MATLAB process calling one gateway (Functions/nd_dwt_3D.m:161,225 -> mex/nd_dwt_mex.c:8): a
 // drop-in multi-GPU path has to live behind that single call.  This file shards the volume in slabs on its outermost axis
 // over `devices[]` (a device may be listed several times: independent slabs and streams on one GPU -- how the path is tested on
-// a one-GPU machine), runs the level loop with the slab entry points of include/ndwt.h and moves the halo planes between
-// slabs with asynchronous device-to-device copies (peer copies over xGMI when the slabs live on different GPUs).  Streams
-// are ordered with events only; the host thread blocks once, at the end of a call.
+// a one-GPU machine), runs the level loop with the slab entry points of include/ndwt.h and moves planes between slabs with
+// asynchronous device-to-device copies (peer copies over xGMI when the slabs live on different GPUs).  Streams are ordered
+// with events only; the host thread blocks once, at the end of a call.
 //
-// Exchange scheme: gather for both directions (analysis: halo planes of the approximation band; synthesis: halo planes of all
-// 2^d bands), which reproduces the single-device result bit for bit with every kernel path of the library.  The one-process-
-// per-GPU driver (sharded.py) additionally has the scatter-add synthesis (1 band of exchange) and the overlap of exchange and
-// interior planes; here the halo copies of a level run on the consumer's stream right before its launch.
+// Data stays where it is: ndwt_mdec / ndwt_mrec take one device pointer per slab (the slab of x on its device, the band-planar
+// coefficient slab on its device) and the kernels read and write them in place -- no plan-owned copy of a slab exists.  The host
+// forms stage whole-volume host arrays through plan-owned slab buffers and call the same code.
+//
+// Exchange per level:
+//   analysis   the halo planes of the approximation band only ((L/2-1) s before, (L/2) s after the slab), copied from their
+//              owners into small buffers / the margins of the approximation scratch: bit-identical to one device.
+//   synthesis  NDWT_EXCHANGE_SCATTER (default where the plan's levels run the fused kernels): every slab synthesises its own
+//              coefficients zero-extended -- its n planes in place, plus the partial sums it owes the (L-1) s planes around it --
+//              and those ONE-band planes are copied to their owners and added (a plane gets its addends in a fixed order, so
+//              results are deterministic; they equal the single-device ones to rounding, the order of summation differs).
+//              NDWT_EXCHANGE_GATHER: the halo planes of all 2^d bands are assembled with the slab in a scratch array (a copy of
+//              every band per level) -- bit-identical to one device, and the path of plans whose levels run per-axis kernels.
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -29,10 +38,24 @@ struct Slab {
     ndwt_plan* plan;
     hipStream_t stream;
     hipEvent_t ready[2];           // "approximation buffer k of this slab is complete" (k = level parity)
-    char* approx[2];               // [halo_max | n | halo_max] planes each: approximation band between levels / x / result
-    char* coef;                    // all bands of the slab: nbt_max * n planes
-    char* gather;                  // synthesis input: 2^d bands * (n + L - 1) planes
+    hipEvent_t margins;            // "the partial sums this slab owes its neighbours are computed" (scatter synthesis)
+    char* approx[2];               // [halo_max | n | halo_max] planes each: the approximation band between levels
+    char* hb;                      // level-1 analysis halos of a device-resident x: halo_max planes before ...
+    char* ha;                      // ... and after the slab
+    char* mb;                      // scatter synthesis: partial sums for the planes before the slab (halo_max planes) ...
+    char* ma;                      // ... and after it
+    char* recv;                    // scatter synthesis: planes received from a neighbour, added and reused (halo_max planes)
+    char* gather;                  // gather synthesis: 2^d bands * (n + L - 1) planes, allocated on first use
+    char* xbuf;                    // host forms: the slab of x / of the result, allocated on first use
+    char* coef;                    // host forms: all bands of the slab, allocated on first use
 };
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_planes_kernel(T* __restrict__ dst, const T* __restrict__ src, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += step) dst[i] += src[i];
+}
 
 }  // namespace
 
@@ -43,8 +66,10 @@ struct ndwt_mplan {
     long long halo_max;            // planes of margin in the approximation buffers
     int L_outer;
     int dilation;
+    int exchange;                  // NDWT_EXCHANGE_*
+    int fast;                      // the slab plans offer the split-halo analysis and the zero-extended synthesis at tap stride 1
     std::vector<Slab> slabs;
-    std::string err;
+    std::string notes;             // peer-access findings of plan creation (ndwt_mplan_describe)
 };
 
 static thread_local std::string g_merr;
@@ -68,8 +93,26 @@ static int mfail(int code, const char* fmt, ...) {
         int rc_ = (expr);                                              \
         if (rc_ != NDWT_OK) return mfail(rc_, "%s", ndwt_last_error()); \
     } while (0)
+#define MRET(expr)                          \
+    do {                                    \
+        int rc_ = (expr);                   \
+        if (rc_ != NDWT_OK) return rc_;     \
+    } while (0)
 
 static long long stride_of(const ndwt_mplan* mp, int lev) { return mp->dilation == NDWT_DILATION_ATROUS ? (1LL << (lev - 1)) : 1LL; }
+
+static Slab* owner_of(ndwt_mplan* mp, long long gp) {
+    for (auto& s : mp->slabs)
+        if (gp >= s.z0 && gp < s.z0 + s.n) return &s;
+    return nullptr;
+}
+
+static int copy_run(ndwt_mplan* mp, Slab& to, char* dst, const Slab& from, const char* src, long long planes) {
+    const size_t bytes = (size_t)planes * mp->plane_bytes;
+    if (from.device == to.device) MHIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, to.stream));
+    else MHIP(hipMemcpyPeerAsync(dst, to.device, src, from.device, bytes, to.stream));
+    return NDWT_OK;
+}
 
 // copy `count` planes starting at GLOBAL plane g (periodic) of a per-slab plane array into dst on slab `to`, on `to`'s stream.
 // plane_ptr(slab, local plane) gives the source address; wait_parity >= 0: wait for the source slab's ready[wait_parity] first.
@@ -78,19 +121,190 @@ static int copy_planes(ndwt_mplan* mp, Slab& to, char* dst, long long g, long lo
     const long long N = mp->dims[mp->ndim - 1];
     long long done = 0;
     while (done < count) {
-        long long gp = ((g + done) % N + N) % N;
-        Slab* src = nullptr;
-        for (auto& s : mp->slabs)
-            if (gp >= s.z0 && gp < s.z0 + s.n) src = &s;
+        const long long gp = ((g + done) % N + N) % N;
+        Slab* src = owner_of(mp, gp);
         if (!src) return mfail(NDWT_ERR_INVALID_ARG, "plane %lld has no owner", gp);
         long long run = src->z0 + src->n - gp;
         if (run > count - done) run = count - done;
         if (wait_parity >= 0 && src != &to) MHIP(hipStreamWaitEvent(to.stream, src->ready[wait_parity], 0));
-        const char* sp = plane_ptr(*src, gp - src->z0);
-        char* dp = dst + (size_t)done * mp->plane_bytes;
-        if (src->device == to.device) MHIP(hipMemcpyAsync(dp, sp, (size_t)run * mp->plane_bytes, hipMemcpyDeviceToDevice, to.stream));
-        else MHIP(hipMemcpyPeerAsync(dp, to.device, sp, src->device, (size_t)run * mp->plane_bytes, to.stream));
+        MRET(copy_run(mp, to, dst + (size_t)done * mp->plane_bytes, *src, plane_ptr(*src, gp - src->z0), run));
         done += run;
+    }
+    return NDWT_OK;
+}
+
+static int add_planes(ndwt_mplan* mp, Slab& s, char* dst, const char* src, long long planes) {
+    const size_t es = mp->dtype == NDWT_F32 ? 4 : 8;
+    const long long n = (long long)((size_t)planes * mp->plane_bytes / es);
+    long long blocks = (n + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks < 1) return NDWT_OK;
+    if (mp->dtype == NDWT_F32) hipLaunchKernelGGL(add_planes_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s.stream, (float*)dst, (const float*)src, n);
+    else hipLaunchKernelGGL(add_planes_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, s.stream, (double*)dst, (const double*)src, n);
+    MHIP(hipGetLastError());
+    return NDWT_OK;
+}
+
+// every stream waits for every slab's ready[k]: the level barrier between slabs (events only, the host does not block)
+static int level_barrier(ndwt_mplan* mp, int k) {
+    for (auto& s : mp->slabs) {
+        MHIP(hipSetDevice(s.device));
+        MHIP(hipEventRecord(s.ready[k], s.stream));
+    }
+    for (auto& s : mp->slabs)
+        for (auto& o : mp->slabs)
+            if (&o != &s) MHIP(hipStreamWaitEvent(s.stream, o.ready[k], 0));
+    return NDWT_OK;
+}
+
+static int sync_all(ndwt_mplan* mp) {
+    for (auto& s : mp->slabs) {
+        MHIP(hipSetDevice(s.device));
+        MHIP(hipStreamSynchronize(s.stream));
+    }
+    return NDWT_OK;
+}
+
+static int lazy_alloc(Slab& s, char** p, size_t bytes) {
+    if (*p) return NDWT_OK;
+    hipError_t e = hipSetDevice(s.device);
+    if (e == hipSuccess) e = hipMalloc((void**)p, bytes);
+    if (e != hipSuccess) return mfail(NDWT_ERR_ALLOC, "device %d: hipMalloc(%zu bytes) failed: %s", s.device, bytes, hipGetErrorString(e));
+    return NDWT_OK;
+}
+
+static int mcheck(const ndwt_mplan* mp, int level) {
+    if (!mp) return mfail(NDWT_ERR_INVALID_ARG, "null plan");
+    if (level < 1 || level > mp->max_level) return mfail(NDWT_ERR_INVALID_ARG, "level %d outside 1..max_level=%d of this plan", level, mp->max_level);
+    return NDWT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ analysis
+// x[i]: the slab of the signal on slab i's device (n_i planes); y[i]: its coefficient slab, band b at b * n_i planes.  Queues the
+// whole transform on the slabs' streams; the caller synchronises.
+static int mdec_core(ndwt_mplan* mp, const void* const* x, void* const* y, int level) {
+    const size_t pb = mp->plane_bytes;
+    const long long H = mp->halo_max;
+    const int nb = mp->nb;
+    for (int lev = 1; lev <= level; ++lev) {
+        const long long st = stride_of(mp, lev);
+        const long long ab = (long long)(mp->L_outer / 2 - 1) * st, aa = (long long)(mp->L_outer / 2) * st;
+        // level lev reads approx[rd] (level 1: the caller's x) and writes its approximation into approx[wr] (the last level: band 0 of y)
+        const int rd = ((lev - 1) & 1) ^ 1, wr = (lev - 1) & 1;
+        size_t i = 0;
+        for (auto& s : mp->slabs) {
+            MHIP(hipSetDevice(s.device));
+            void* outs[16];
+            outs[0] = lev == level ? y[i] : (void*)(s.approx[wr] + (size_t)H * pb);
+            for (int b = 1; b < nb; ++b) outs[b] = (char*)y[i] + (size_t)((1 + (nb - 1) * (level - lev) + (b - 1)) * s.n) * pb;
+            if (lev == 1) {
+                // the slab of x is read where it lies; its halo planes come from the neighbours' slabs of x
+                auto src = [&](Slab& o, long long lp) -> const char* { return (const char*)x[&o - &mp->slabs[0]] + (size_t)lp * pb; };
+                if (mp->fast && st == 1) {
+                    MRET(copy_planes(mp, s, s.hb, s.z0 - ab, ab, src, -1));
+                    MRET(copy_planes(mp, s, s.ha, s.z0 + s.n, aa, src, -1));
+                    MTRY(ndwt_analysis_level_slab_split(s.plan, x[i], ab ? s.hb : nullptr, s.ha, outs, 1, s.stream));
+                } else {                                  // kernels that want the halo planes in line with the slab: one copy of the slab
+                    char* mid = s.approx[rd] + (size_t)H * pb;
+                    MRET(copy_planes(mp, s, mid - (size_t)ab * pb, s.z0 - ab, ab + s.n + aa, src, -1));
+                    MTRY(ndwt_analysis_level_slab(s.plan, mid - (size_t)ab * pb, outs, (int)st, s.stream));
+                }
+            } else {
+                char* mid = s.approx[rd] + (size_t)H * pb;   // produced in place by level lev - 1; the margins take the neighbours' planes
+                auto src = [&](Slab& o, long long lp) -> const char* { return o.approx[rd] + (size_t)(H + lp) * pb; };
+                MRET(copy_planes(mp, s, mid - (size_t)ab * pb, s.z0 - ab, ab, src, -1));   // (producers: waited for at the end of level lev - 1)
+                MRET(copy_planes(mp, s, mid + (size_t)s.n * pb, s.z0 + s.n, aa, src, -1));
+                MTRY(ndwt_analysis_level_slab(s.plan, mid - (size_t)ab * pb, outs, (int)st, s.stream));
+            }
+            ++i;
+        }
+        // approx[wr] of every slab is complete, and approx[rd] free to be overwritten by level lev + 1, once every slab's work of this
+        // level (its launch and its halo copies out of the neighbours' buffers) is done
+        MRET(level_barrier(mp, wr));
+    }
+    return NDWT_OK;
+}
+
+// ----------------------------------------------------------------------------------------------- synthesis
+// partial sums of `count` planes starting at global plane g (periodic), held in `buf` on slab `from`: to their owners, added there.
+// dst_of(slab) = where that slab's n planes of this level's result live.
+template <class DstFn>
+static int scatter_margin(ndwt_mplan* mp, Slab& from, const char* buf, long long g, long long count, DstFn dst_of) {
+    const long long N = mp->dims[mp->ndim - 1];
+    long long done = 0;
+    while (done < count) {
+        const long long gp = ((g + done) % N + N) % N;
+        Slab* to = owner_of(mp, gp);
+        if (!to) return mfail(NDWT_ERR_INVALID_ARG, "plane %lld has no owner", gp);
+        long long run = to->z0 + to->n - gp;
+        if (run > count - done) run = count - done;
+        MHIP(hipSetDevice(to->device));
+        if (to != &from) MHIP(hipStreamWaitEvent(to->stream, from.margins, 0));
+        const char* src = buf + (size_t)done * mp->plane_bytes;
+        char* dst = dst_of(*to) + (size_t)(gp - to->z0) * mp->plane_bytes;
+        if (to->device == from.device) {                  // same memory: add straight from the producer's buffer
+            MRET(add_planes(mp, *to, dst, src, run));
+        } else {
+            MRET(copy_run(mp, *to, to->recv, from, src, run));
+            MRET(add_planes(mp, *to, dst, to->recv, run));
+        }
+        done += run;
+    }
+    return NDWT_OK;
+}
+
+static int mrec_core(ndwt_mplan* mp, const void* const* y, void* const* x, int level) {
+    const size_t pb = mp->plane_bytes;
+    const long long H = mp->halo_max;
+    const int nb = mp->nb;
+    for (int ind = 1; ind <= level; ++ind) {
+        const int lev = level - ind + 1;
+        const long long st = stride_of(mp, lev);
+        const long long sb = (long long)(mp->L_outer / 2) * st, sa = (long long)(mp->L_outer / 2 - 1) * st;
+        const int rd = ind & 1, wr = rd ^ 1;             // level index ind > 1 reads the approximation level ind - 1 wrote into approx[rd]
+        const bool scatter = mp->exchange == NDWT_EXCHANGE_SCATTER && mp->fast && st == 1;
+        auto band_ptr = [&](size_t i, Slab& o, int b) -> const char* {
+            if (b == 0) return ind == 1 ? (const char*)y[i] : o.approx[rd] + (size_t)H * pb;
+            return (const char*)y[i] + (size_t)((1 + (long long)(nb - 1) * (level - lev) + (b - 1)) * o.n) * pb;
+        };
+        auto dst_of = [&](Slab& o) -> char* { return lev == 1 ? (char*)x[&o - &mp->slabs[0]] : o.approx[wr] + (size_t)H * pb; };
+        if (scatter) {
+            // zero-extended synthesis: plane k of the extended result = global plane z0 - sa + k.  The slab's own n planes go where
+            // the result lives; the sa planes before and the sb planes after it are partial sums owed to their owners.
+            size_t i = 0;
+            for (auto& s : mp->slabs) {
+                MHIP(hipSetDevice(s.device));
+                const void* ins[16];
+                for (int b = 0; b < nb; ++b) ins[b] = band_ptr(i, s, b);
+                MTRY(ndwt_synthesis_level_slab_part(s.plan, ins, s.n, sa, s.n, dst_of(s), 1, s.stream));
+                if (sa) MTRY(ndwt_synthesis_level_slab_part(s.plan, ins, s.n, 0, sa, s.mb, 1, s.stream));
+                MTRY(ndwt_synthesis_level_slab_part(s.plan, ins, s.n, sa + s.n, sb, s.ma, 1, s.stream));
+                MHIP(hipEventRecord(s.margins, s.stream));
+                ++i;
+            }
+            // a destination's own planes are written by its own stream before anything is added to them (stream order); the addends
+            // arrive in slab order, "before" margins first: a fixed order of summation
+            for (auto& s : mp->slabs) {
+                if (sa) MRET(scatter_margin(mp, s, s.mb, s.z0 - sa, sa, dst_of));
+                MRET(scatter_margin(mp, s, s.ma, s.z0 + s.n, sb, dst_of));
+            }
+        } else {
+            for (auto& s : mp->slabs) {
+                MHIP(hipSetDevice(s.device));
+                const long long nh = s.n + sb + sa;
+                const long long smax = mp->dilation == NDWT_DILATION_ATROUS ? (1LL << (mp->max_level - 1)) : 1LL;
+                MRET(lazy_alloc(s, &s.gather, (size_t)((long long)nb * (s.n + (long long)(mp->L_outer - 1) * smax)) * pb));
+                const void* ins[16];
+                for (int b = 0; b < nb; ++b) {
+                    char* dst = s.gather + (size_t)((long long)b * nh) * pb;
+                    ins[b] = dst;
+                    auto src = [&, b](Slab& o, long long lp) -> const char* { return band_ptr(&o - &mp->slabs[0], o, b) + (size_t)lp * pb; };
+                    MRET(copy_planes(mp, s, dst, s.z0 - sb, nh, src, -1));   // all producers were waited for at the end of the previous level
+                }
+                MTRY(ndwt_synthesis_level_slab(s.plan, ins, dst_of(s), (int)st, s.stream));
+            }
+        }
+        MRET(level_barrier(mp, wr));
     }
     return NDWT_OK;
 }
@@ -109,6 +323,7 @@ int ndwt_mplan_create(ndwt_mplan** out, int ndim, const int64_t* dims, const cha
     ndwt_mplan* mp = new ndwt_mplan();
     mp->ndim = ndim; mp->dtype = dtype; mp->complexity = complexity; mp->max_level = max_level; mp->nb = 1 << ndim;
     mp->dilation = dilation;
+    mp->exchange = NDWT_EXCHANGE_SCATTER;
     for (int a = 0; a < ndim; ++a) mp->dims[a] = dims[a];
     size_t pb = (dtype == NDWT_F32 ? 4 : 8) * (complexity == NDWT_COMPLEX_INTERLEAVED ? 2 : 1);
     for (int a = 0; a + 1 < ndim; ++a) pb *= (size_t)dims[a];
@@ -119,7 +334,6 @@ int ndwt_mplan_create(ndwt_mplan** out, int ndim, const int64_t* dims, const cha
     mp->L_outer = L;
     const long long smax = dilation == NDWT_DILATION_ATROUS ? (1LL << (max_level - 1)) : 1LL;
     mp->halo_max = (long long)(L / 2) * smax;
-    const long long nbt = (long long)ndwt_num_bands(ndim, max_level);
     std::vector<int64_t> ld(dims, dims + ndim);
     for (int i = 0; i < ndev; ++i) {
         Slab s;
@@ -130,21 +344,33 @@ int ndwt_mplan_create(ndwt_mplan** out, int ndim, const int64_t* dims, const cha
         mp->slabs.push_back(s);
     }
     int rc = NDWT_OK;
+    mp->fast = 1;
     for (auto& s : mp->slabs) {
         ld[ndim - 1] = s.n;
         if ((rc = ndwt_plan_create_slab(&s.plan, ndim, ld.data(), N, wnames, dtype, complexity, pres_l2_norm, dilation, 1, s.device)) != NDWT_OK) break;
+        if (!ndwt_plan_slab_fast(s.plan)) mp->fast = 0;
         hipError_t e = hipSetDevice(s.device);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
         for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&s.ready[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.margins, hipEventDisableTiming);
         for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipMalloc((void**)&s.approx[k], (size_t)(s.n + 2 * mp->halo_max) * pb);
-        if (e == hipSuccess) e = hipMalloc((void**)&s.coef, (size_t)(nbt * s.n) * pb);
-        if (e == hipSuccess) e = hipMalloc((void**)&s.gather, (size_t)((long long)mp->nb * (s.n + (long long)(L - 1) * smax)) * pb);
+        for (char** p : {&s.hb, &s.ha, &s.mb, &s.ma, &s.recv})
+            if (e == hipSuccess) e = hipMalloc((void**)p, (size_t)mp->halo_max * pb);
         if (e != hipSuccess) { rc = mfail(NDWT_ERR_ALLOC, "device %d: %s", s.device, hipGetErrorString(e)); break; }
         for (auto& o : mp->slabs)                        // peer access where the runtime offers it (same-device pairs need none)
             if (o.device != s.device) {
                 int can = 0;
-                if (hipDeviceCanAccessPeer(&can, s.device, o.device) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(o.device, 0);
-                (void)hipGetLastError();                 // "already enabled" is not an error
+                hipError_t pe = hipDeviceCanAccessPeer(&can, s.device, o.device);
+                if (pe == hipSuccess && can) {
+                    pe = hipDeviceEnablePeerAccess(o.device, 0);
+                    if (pe == hipErrorPeerAccessAlreadyEnabled) pe = hipSuccess;
+                }
+                (void)hipGetLastError();
+                if (pe != hipSuccess || !can) {           // the copies still work (staged by the runtime), slower: say so
+                    char note[160];
+                    snprintf(note, sizeof note, "no peer access %d -> %d (%s); ", s.device, o.device, pe != hipSuccess ? hipGetErrorString(pe) : "not offered");
+                    if (mp->notes.find(note) == std::string::npos) mp->notes += note;
+                }
             }
     }
     if (rc != NDWT_OK) {
@@ -166,8 +392,9 @@ int ndwt_mplan_destroy(ndwt_mplan* mp) {
             if (s.approx[k]) (void)hipFree(s.approx[k]);
             if (s.ready[k]) (void)hipEventDestroy(s.ready[k]);
         }
-        if (s.coef) (void)hipFree(s.coef);
-        if (s.gather) (void)hipFree(s.gather);
+        if (s.margins) (void)hipEventDestroy(s.margins);
+        for (char* p : {s.hb, s.ha, s.mb, s.ma, s.recv, s.gather, s.xbuf, s.coef})
+            if (p) (void)hipFree(p);
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
     delete mp;
@@ -184,66 +411,82 @@ int ndwt_mplan_slab(const ndwt_mplan* mp, int idx, int* device, int64_t* first_p
     return NDWT_OK;
 }
 
-static int mcheck(const ndwt_mplan* mp, int level) {
-    if (!mp) return mfail(NDWT_ERR_INVALID_ARG, "null plan");
-    if (level < 1 || level > mp->max_level) return mfail(NDWT_ERR_INVALID_ARG, "level %d outside 1..max_level=%d of this plan", level, mp->max_level);
+int ndwt_mplan_set_exchange(ndwt_mplan* mp, int exchange) {
+    if (!mp || (exchange != NDWT_EXCHANGE_SCATTER && exchange != NDWT_EXCHANGE_GATHER)) return mfail(NDWT_ERR_INVALID_ARG, "bad plan / exchange scheme");
+    mp->exchange = exchange;
     return NDWT_OK;
+}
+
+int ndwt_mplan_describe(const ndwt_mplan* mp, char* buf, int buflen) {
+    if (!mp || !buf || buflen < 1) return mfail(NDWT_ERR_INVALID_ARG, "bad arguments");
+    const bool scatter = mp->exchange == NDWT_EXCHANGE_SCATTER && mp->fast && mp->dilation == NDWT_DILATION_REFERENCE;
+    snprintf(buf, (size_t)buflen, "%d slabs; analysis: halo planes of the approximation band%s; synthesis: %s; %s", (int)mp->slabs.size(),
+             mp->fast ? ", slabs read in place" : "", scatter ? "scatter-add of one band of partial sums" : "gather of the halo planes of all bands",
+             mp->notes.empty() ? "peer access between all devices" : mp->notes.c_str());
+    return NDWT_OK;
+}
+
+// device-resident form: x_slabs[i] / y_slabs[i] live on slab i's device (ndwt_mplan_slab: n_i planes of x; band b of the coefficient
+// slab at b * n_i planes).  The data must be complete when the call is made (no stream of the caller is waited for); the call returns
+// when the result is.
+int ndwt_mdec(ndwt_mplan* mp, const void* const* x_slabs, void* const* y_slabs, int level) {
+    int rc = mcheck(mp, level);
+    if (rc) return rc;
+    if (!x_slabs || !y_slabs) return mfail(NDWT_ERR_INVALID_ARG, "null pointer array");
+    for (size_t i = 0; i < mp->slabs.size(); ++i)
+        if (!x_slabs[i] || !y_slabs[i]) return mfail(NDWT_ERR_INVALID_ARG, "null slab pointer %zu", i);
+    rc = mdec_core(mp, x_slabs, y_slabs, level);
+    const int rs = sync_all(mp);                          // (also after an error: nothing stays queued on buffers the caller owns)
+    return rc ? rc : rs;
+}
+
+int ndwt_mrec(ndwt_mplan* mp, const void* const* y_slabs, void* const* x_slabs, int level) {
+    int rc = mcheck(mp, level);
+    if (rc) return rc;
+    if (!x_slabs || !y_slabs) return mfail(NDWT_ERR_INVALID_ARG, "null pointer array");
+    for (size_t i = 0; i < mp->slabs.size(); ++i)
+        if (!x_slabs[i] || !y_slabs[i]) return mfail(NDWT_ERR_INVALID_ARG, "null slab pointer %zu", i);
+    rc = mrec_core(mp, y_slabs, x_slabs, level);
+    const int rs = sync_all(mp);
+    return rc ? rc : rs;
 }
 
 // whole-volume host arrays in, whole-volume host arrays out (the layout the MATLAB gateway holds): x is prod(dims) elements,
 // y prod(dims) * ndwt_num_bands(ndim, level), band-planar.  Blocks until the result is in y.
+static int host_buffers(ndwt_mplan* mp, std::vector<void*>& xs, std::vector<void*>& ys) {
+    const long long nbt = (long long)ndwt_num_bands(mp->ndim, mp->max_level);
+    for (auto& s : mp->slabs) {
+        MRET(lazy_alloc(s, &s.xbuf, (size_t)s.n * mp->plane_bytes));
+        MRET(lazy_alloc(s, &s.coef, (size_t)(nbt * s.n) * mp->plane_bytes));
+        xs.push_back(s.xbuf);
+        ys.push_back(s.coef);
+    }
+    return NDWT_OK;
+}
+
 int ndwt_mdec_host(ndwt_mplan* mp, const void* x_host, void* y_host, int level) {
     int rc = mcheck(mp, level);
     if (rc) return rc;
     if (!x_host || !y_host) return mfail(NDWT_ERR_INVALID_ARG, "null data pointer");
     const size_t pb = mp->plane_bytes;
-    const long long N = mp->dims[mp->ndim - 1], H = mp->halo_max;
-    const int nb = mp->nb;
+    const long long N = mp->dims[mp->ndim - 1];
     const long long nbt = (long long)ndwt_num_bands(mp->ndim, level);
-    // the signal into the middle of approx[1] (the input of level 1: parity of level 0 is 0 -> buffer index (lev-1)&1 ^ 1 ...)
-    // buffer that level `lev` READS: in_buf(lev) = approx[(lev - 1) & 1 ^ 1]; it WRITES its approximation into approx[(lev - 1) & 1]
+    std::vector<void*> xs, ys;
+    MRET(host_buffers(mp, xs, ys));
     for (auto& s : mp->slabs) {
         MHIP(hipSetDevice(s.device));
-        MHIP(hipMemcpyAsync(s.approx[1] + (size_t)H * pb, (const char*)x_host + (size_t)s.z0 * pb, (size_t)s.n * pb, hipMemcpyHostToDevice, s.stream));
-        MHIP(hipEventRecord(s.ready[1], s.stream));
+        MHIP(hipMemcpyAsync(s.xbuf, (const char*)x_host + (size_t)s.z0 * pb, (size_t)s.n * pb, hipMemcpyHostToDevice, s.stream));
     }
-    for (int lev = 1; lev <= level; ++lev) {
-        const long long st = stride_of(mp, lev);
-        const long long ab = (long long)(mp->L_outer / 2 - 1) * st, aa = (long long)(mp->L_outer / 2) * st;
-        const int rd = ((lev - 1) & 1) ^ 1, wr = (lev - 1) & 1;
+    MRET(level_barrier(mp, 1));                           // every slab of x is in place before a neighbour reads its halo planes
+    rc = mdec_core(mp, xs.data(), ys.data(), level);
+    if (rc == NDWT_OK)
         for (auto& s : mp->slabs) {
             MHIP(hipSetDevice(s.device));
-            char* mid = s.approx[rd] + (size_t)H * pb;
-            auto src = [&](Slab& o, long long lp) -> const char* { return o.approx[rd] + (size_t)(H + lp) * pb; };
-            MTRY(copy_planes(mp, s, mid - (size_t)ab * pb, s.z0 - ab, ab, src, rd));
-            MTRY(copy_planes(mp, s, mid + (size_t)s.n * pb, s.z0 + s.n, aa, src, rd));
-            // WAR: this level overwrites approx[wr], which the neighbours may still be copying from (their level lev-1 halos):
-            // they recorded ready[...]? no -- they READ it on THEIR streams; wait until they have issued level lev's copies below
-            void* outs[16];
-            outs[0] = lev == level ? (void*)s.coef : (void*)(s.approx[wr] + (size_t)H * pb);
-            for (int b = 1; b < nb; ++b) outs[b] = s.coef + (size_t)((1 + (nb - 1) * (level - lev) + (b - 1)) * s.n) * pb;
-            MTRY(ndwt_analysis_level_slab(s.plan, mid - (size_t)ab * pb, outs, (int)st, s.stream));
+            for (long long b = 0; b < nbt; ++b)
+                MHIP(hipMemcpyAsync((char*)y_host + (size_t)(b * N + s.z0) * pb, s.coef + (size_t)(b * s.n) * pb, (size_t)s.n * pb, hipMemcpyDeviceToHost, s.stream));
         }
-        // a slab's approx[wr] is complete once its launch is; its approx[rd] may be overwritten (level lev + 1 writes it) only
-        // after every slab's halo copies of THIS level are done: order both with one event per slab recorded after the launch
-        for (auto& s : mp->slabs) {
-            MHIP(hipSetDevice(s.device));
-            MHIP(hipEventRecord(s.ready[wr], s.stream));
-        }
-        for (auto& s : mp->slabs)                        // every stream waits for every slab's level-lev work before level lev + 1
-            for (auto& o : mp->slabs)
-                if (&o != &s) MHIP(hipStreamWaitEvent(s.stream, o.ready[wr], 0));
-    }
-    for (auto& s : mp->slabs) {
-        MHIP(hipSetDevice(s.device));
-        for (long long b = 0; b < nbt; ++b)
-            MHIP(hipMemcpyAsync((char*)y_host + (size_t)(b * N + s.z0) * pb, s.coef + (size_t)(b * s.n) * pb, (size_t)s.n * pb, hipMemcpyDeviceToHost, s.stream));
-    }
-    for (auto& s : mp->slabs) {
-        MHIP(hipSetDevice(s.device));
-        MHIP(hipStreamSynchronize(s.stream));
-    }
-    return NDWT_OK;
+    const int rs = sync_all(mp);
+    return rc ? rc : rs;
 }
 
 int ndwt_mrec_host(ndwt_mplan* mp, const void* y_host, void* x_host, int level) {
@@ -251,58 +494,24 @@ int ndwt_mrec_host(ndwt_mplan* mp, const void* y_host, void* x_host, int level) 
     if (rc) return rc;
     if (!x_host || !y_host) return mfail(NDWT_ERR_INVALID_ARG, "null data pointer");
     const size_t pb = mp->plane_bytes;
-    const long long N = mp->dims[mp->ndim - 1], H = mp->halo_max;
-    const int nb = mp->nb;
+    const long long N = mp->dims[mp->ndim - 1];
     const long long nbt = (long long)ndwt_num_bands(mp->ndim, level);
-    for (auto& s : mp->slabs) {                          // coefficients to the slabs; band 0 also into approx[1] (the running approximation)
+    std::vector<void*> xs, ys;
+    MRET(host_buffers(mp, xs, ys));
+    for (auto& s : mp->slabs) {
         MHIP(hipSetDevice(s.device));
         for (long long b = 0; b < nbt; ++b)
             MHIP(hipMemcpyAsync(s.coef + (size_t)(b * s.n) * pb, (const char*)y_host + (size_t)(b * N + s.z0) * pb, (size_t)s.n * pb, hipMemcpyHostToDevice, s.stream));
-        MHIP(hipMemcpyAsync(s.approx[1] + (size_t)H * pb, s.coef, (size_t)s.n * pb, hipMemcpyDeviceToDevice, s.stream));
-        MHIP(hipEventRecord(s.ready[1], s.stream));
     }
-    for (auto& s : mp->slabs)
-        for (auto& o : mp->slabs)
-            if (&o != &s) MHIP(hipStreamWaitEvent(s.stream, o.ready[1], 0));
-    for (int ind = 1; ind <= level; ++ind) {
-        const int lev = level - ind + 1;
-        const long long st = stride_of(mp, lev);
-        const long long sb = (long long)(mp->L_outer / 2) * st, sa = (long long)(mp->L_outer / 2 - 1) * st;
-        const int rd = (ind & 1), wr = rd ^ 1;           // ind = 1 reads approx[1]
+    MRET(level_barrier(mp, 1));
+    rc = mrec_core(mp, ys.data(), xs.data(), level);
+    if (rc == NDWT_OK)
         for (auto& s : mp->slabs) {
             MHIP(hipSetDevice(s.device));
-            const long long nh = s.n + sb + sa;
-            const void* ins[16];
-            for (int b = 0; b < nb; ++b) {
-                char* dst = s.gather + (size_t)((long long)b * nh) * pb;
-                ins[b] = dst;
-                const long long slot = b == 0 ? -1 : 1 + (long long)(nb - 1) * (level - lev) + (b - 1);
-                auto src = [&, slot](Slab& o, long long lp) -> const char* {
-                    return slot < 0 ? o.approx[rd] + (size_t)(H + lp) * pb : o.coef + (size_t)(slot * o.n + lp) * pb;
-                };
-                MTRY(copy_planes(mp, s, dst, s.z0 - sb, nh, src, -1));   // all producers were waited for at the end of the previous level
-            }
-            void* out = s.approx[wr] + (size_t)H * pb;
-            MTRY(ndwt_synthesis_level_slab(s.plan, ins, out, (int)st, s.stream));
+            MHIP(hipMemcpyAsync((char*)x_host + (size_t)s.z0 * pb, s.xbuf, (size_t)s.n * pb, hipMemcpyDeviceToHost, s.stream));
         }
-        for (auto& s : mp->slabs) {
-            MHIP(hipSetDevice(s.device));
-            MHIP(hipEventRecord(s.ready[wr], s.stream));
-        }
-        for (auto& s : mp->slabs)
-            for (auto& o : mp->slabs)
-                if (&o != &s) MHIP(hipStreamWaitEvent(s.stream, o.ready[wr], 0));
-    }
-    const int fin = (level & 1) ^ 1;                     // buffer the last level wrote
-    for (auto& s : mp->slabs) {
-        MHIP(hipSetDevice(s.device));
-        MHIP(hipMemcpyAsync((char*)x_host + (size_t)s.z0 * pb, s.approx[fin] + (size_t)H * pb, (size_t)s.n * pb, hipMemcpyDeviceToHost, s.stream));
-    }
-    for (auto& s : mp->slabs) {
-        MHIP(hipSetDevice(s.device));
-        MHIP(hipStreamSynchronize(s.stream));
-    }
-    return NDWT_OK;
+    const int rs = sync_all(mp);
+    return rc ? rc : rs;
 }
 
 const char* ndwt_mplan_last_error(void) { return g_merr.c_str(); }

@@ -837,6 +837,8 @@ def test_single_process_multi_device_plan(dims, wn, level, precision, cplx, dila
     mp = api.MultiPlan(dims, wn, tdt, [0] * nslab, cplx, True, dilation, max_level=level)
     sl = mp.slabs()
     assert len(sl) == nslab and sl[0][1] == 0 and sum(s[2] for s in sl) == dims[-1]
+    scatter = "scatter-add" in mp.describe()              # fused 3-D plans at tap stride 1; everything else gathers anyway
+    assert scatter == (d == 3 and exact) and "peer access between all devices" in mp.describe()
     yk = mp.dec(xk, level)
     want = orc.spatial_dec(x, wn, level, 1, dilation)
     assert _relerr(yk.T, want) <= TOL[precision]
@@ -844,14 +846,30 @@ def test_single_process_multi_device_plan(dims, wn, level, precision, cplx, dila
     p1 = api.Plan(dims, wn, tdt, cplx, True, dilation, max_level=level)
     y1 = np.empty_like(yk)
     ndwt._lib.check(ndwt.lib().ndwt_dec_host(p1._h, xk.ctypes.data_as(ctypes.c_void_p), y1.ctypes.data_as(ctypes.c_void_p), level))
-    assert np.array_equal(yk, y1) if exact else _relerr(yk, y1) <= TOL[precision]
+    assert np.array_equal(yk, y1) if exact else _relerr(yk, y1) <= TOL[precision]     # analysis: halo planes gathered, bit-identical
     c = (rng.standard_normal(yk.shape) + (1j * rng.standard_normal(yk.shape) if cplx else 0)).astype(cdt)
-    r = mp.rec(c)
-    r1 = np.empty_like(r)
+    r1 = np.empty(xk.shape, dtype=cdt)
     ndwt._lib.check(ndwt.lib().ndwt_rec_host(p1._h, c.ctypes.data_as(ctypes.c_void_p), r1.ctypes.data_as(ctypes.c_void_p), level))
-    assert np.array_equal(r, r1) if exact else _relerr(r, r1) <= 4 * TOL[precision]
-    assert _relerr(r.T, orc.spatial_rec(np.transpose(c), wn, 1, dilation)) <= 4 * TOL[precision]
-    assert _relerr(mp.rec(yk), xk) <= 20 * TOL[precision]
+    for scheme in ("scatter", "gather"):
+        mp.set_exchange(scheme)
+        r = mp.rec(c)
+        # gather reproduces one device bit for bit; the scatter-add synthesis sums the same products in another order
+        bitwise = exact and (scheme == "gather" or not scatter)
+        assert np.array_equal(r, r1) if bitwise else _relerr(r, r1) <= 4 * TOL[precision], scheme
+        assert _relerr(r.T, orc.spatial_rec(np.transpose(c), wn, 1, dilation)) <= 4 * TOL[precision]
+        assert np.array_equal(r, mp.rec(c))                                           # deterministic: a fixed order of summation
+        assert _relerr(mp.rec(yk), xk) <= 20 * TOL[precision]
+    mp.set_exchange("scatter")
+    # device-resident form: one tensor per slab, read and written in place
+    dev = torch.device("cuda", 0)
+    xs = [torch.from_numpy(xk[z0:z0 + n]).to(dev) for _, z0, n in sl]
+    ys = mp.dec_device(xs, level)
+    assert all(np.array_equal(yd.cpu().numpy(), yk[:, z0:z0 + n]) for yd, (_, z0, n) in zip(ys, sl))
+    assert all(torch.equal(xd, torch.from_numpy(xk[z0:z0 + n]).to(dev)) for xd, (_, z0, n) in zip(xs, sl))     # inputs untouched
+    cs = [torch.from_numpy(np.ascontiguousarray(c[:, z0:z0 + n])).to(dev) for _, z0, n in sl]
+    rs = mp.rec_device(cs)
+    r = mp.rec(c)
+    assert all(np.array_equal(rd.cpu().numpy(), r[z0:z0 + n]) for rd, (_, z0, n) in zip(rs, sl))
     with pytest.raises(ndwt.NdwtError, match="max_level"):
         mp.dec(xk, level + 1)
     # the same through the class API: the 'devices' option of the drop-in classes (host arrays, compute = 'hip_off')
@@ -946,3 +964,43 @@ def test_denoise_with_fused_level1_against_numpy(sizes, wn, level, l2):
             bad = np.abs(got.cpu().numpy() - a) > 2e-5 * scale
             assert bad.mean() <= frac, (name, mode, float(np.abs(got.cpu().numpy() - a).max()))
     assert _relerr(w.denoise(xg, level, 0.0).cpu().numpy(), x) < 20 * TOL["single"]      # threshold 0 = identity
+
+
+def test_one_plan_serves_several_torch_streams():
+    """the classes keep ONE plan per (data kind, device); a call on another torch stream first waits for the work the plan's previous
+    stream still has queued (the plan's scratch is never shared by two streams in flight, and no scratch accumulates per stream)"""
+    sizes = [96, 64, 48]
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(sizes)
+    w = ndwt.nd_dwt_3D("db4", sizes, "pres_l2_norm", 1, "precision", "single")
+    xg = _colmajor_gpu(x, "single")
+    want = w.dec(xg, 3)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    outs = []
+    for rep in range(4):
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                y = w.dec(xg, 3)
+                outs.append((y, w.rec(y)))
+    torch.cuda.synchronize()
+    assert len(w._plans) == 1
+    for y, r in outs:
+        assert torch.equal(y, want)
+        assert _relerr(r.cpu().numpy(), x) < 20 * TOL["single"]
+
+
+def test_sharded_driver_band_pitch_option():
+    """ShardedNdDwt(band_pitch='packed') returns a contiguous coefficient slab (for callers that pass it to collectives or take raw
+    pointers); the default 'auto' returns the pitched view; the values are the same"""
+    sh = __import__("importlib").import_module("non-decimated_wavelets_amd.sharded")
+    dev = torch.device("cuda", 0)
+    x = torch.randn(24, 40, 72, device=dev)
+    a = sh.ShardedNdDwt("db4", [72, 40, 24], pres_l2_norm=True, precision="single", device=dev)
+    b = sh.ShardedNdDwt("db4", [72, 40, 24], pres_l2_norm=True, precision="single", device=dev, band_pitch="packed")
+    ya, yb = a.dec(x, 2), b.dec(x, 2)
+    assert yb.is_contiguous() and not ya.is_contiguous() and torch.equal(ya, yb)
+    assert torch.equal(a.rec(ya), b.rec(yb)) and yb.view(-1).numel() == yb.numel()
+    with pytest.raises(ValueError, match="band_pitch"):
+        sh.ShardedNdDwt("db4", [72, 40, 24], device=dev, band_pitch="odd")
