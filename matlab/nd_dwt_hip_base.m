@@ -15,7 +15,7 @@ classdef (Abstract) nd_dwt_hip_base
         compute = 'hip';
         precision = 'double';
         dilation = 'reference';     % 'atrous': textbook SWT (taps dilated by 2^(level-1)); the reference never dilates
-        devices = [];               % HIP device ordinals to shard the outermost axis over (2-D .. 4-D); empty: device 0
+        devices = [];               % HIP device ordinals: empty = device 0, one = that device, several = the outermost axis sharded over them (2-D .. 4-D)
     end
     methods (Abstract, Access = protected)
         d = ndim_(obj)                       % number of dimensions

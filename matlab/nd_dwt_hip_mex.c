@@ -31,7 +31,7 @@
 
 typedef struct {
     ndwt_plan* plan;
-    int ndim, dtype, cplx, l2, dilation, max_level;
+    int ndim, dtype, cplx, l2, dilation, max_level, device;
     int64_t dims[NDWT_MAX_DIMS];
     char names[NDWT_MAX_DIMS][16];
     unsigned long stamp; /* last use, for eviction */
@@ -52,7 +52,7 @@ static void release_plans(void) {
 static void fail(const char* what) { mexErrMsgIdAndTxt(ERR_ID, "%s: %s", what, ndwt_last_error()); }
 
 /* the cached plan of this configuration (created, or re-created with more levels, when needed) */
-static ndwt_plan* get_plan(int ndim, const int64_t* dims, char names[][16], int dtype, int cplx, int l2, int dilation, int level) {
+static ndwt_plan* get_plan(int ndim, const int64_t* dims, char names[][16], int dtype, int cplx, int l2, int dilation, int level, int device) {
     int i, a, victim = 0;
     const char* wn[NDWT_MAX_DIMS];
     if (!g_at_exit) {
@@ -61,7 +61,7 @@ static ndwt_plan* get_plan(int ndim, const int64_t* dims, char names[][16], int 
     }
     for (i = 0; i < NCACHE; ++i) {
         cached_plan* c = &g_cache[i];
-        int same = c->plan && c->ndim == ndim && c->dtype == dtype && c->cplx == cplx && c->l2 == l2 && c->dilation == dilation;
+        int same = c->plan && c->ndim == ndim && c->dtype == dtype && c->cplx == cplx && c->l2 == l2 && c->dilation == dilation && c->device == device;
         for (a = 0; same && a < ndim; ++a) same = c->dims[a] == dims[a] && !strcmp(c->names[a], names[a]);
         if (same && c->max_level >= level) {
             c->stamp = ++g_clock;
@@ -84,7 +84,7 @@ build:
     if (g_cache[victim].plan) ndwt_plan_destroy(g_cache[victim].plan);
     g_cache[victim].plan = NULL;
     for (a = 0; a < ndim; ++a) wn[a] = names[a];
-    if (ndwt_plan_create(&g_cache[victim].plan, ndim, dims, wn, dtype, cplx, l2, dilation, level < 3 ? 3 : level, 0) != NDWT_OK) {
+    if (ndwt_plan_create(&g_cache[victim].plan, ndim, dims, wn, dtype, cplx, l2, dilation, level < 3 ? 3 : level, device) != NDWT_OK) {
         g_cache[victim].plan = NULL;
         fail("plan");
     }
@@ -93,6 +93,7 @@ build:
     g_cache[victim].cplx = cplx;
     g_cache[victim].l2 = l2;
     g_cache[victim].dilation = dilation;
+    g_cache[victim].device = device;
     g_cache[victim].max_level = level < 3 ? 3 : level;
     for (a = 0; a < ndim; ++a) {
         g_cache[victim].dims[a] = dims[a];
@@ -207,16 +208,18 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
 #else
     cplx = NDWT_REAL;                                    /* split storage: one real transform per part */
 #endif
-    plan = ndev > 0 ? NULL : get_plan(ndim, dims, names, dtype, cplx, l2, dilation, level);
+    /* no `devices`: device 0; ONE ordinal: the single-device plan on that device; several: the multi-device plan */
+    plan = ndev > 1 ? NULL : get_plan(ndim, dims, names, dtype, cplx, l2, dilation, level, ndev == 1 ? devices[0] : 0);
 
-    /* output: MATLAB-owned, like mxCreateNumericArray at nd_dwt_mex.c:86,136 */
+    /* output: MATLAB-owned like the reference's (nd_dwt_mex.c:86,136), but NOT zero-filled: every element is written by the
+     * transform (the reference needs the zeros, nddwt.c:168-173 accumulates into them; 11.8 GB of memset for a 512^3 3-level dec) */
     for (a = 0; a < ndim; ++a) od[a] = (mwSize)dims[a];
     ond = (mwSize)ndim;
     if (!inverse) od[ond++] = (mwSize)ndwt_num_bands(ndim, level);
     if (ond == 1) od[ond++] = 1;
-    plhs[0] = mxCreateNumericArray(ond, od, mxIsSingle(x) ? mxSINGLE_CLASS : mxDOUBLE_CLASS, mxIsComplex(x) ? mxCOMPLEX : mxREAL);
+    plhs[0] = mxCreateUninitNumericArray(ond, od, mxIsSingle(x) ? mxSINGLE_CLASS : mxDOUBLE_CLASS, mxIsComplex(x) ? mxCOMPLEX : mxREAL);
 
-    if (ndev > 0) {   /* sharded over the listed devices by the single-process multi-device plan */
+    if (ndev > 1) {   /* sharded over the listed devices by the single-process multi-device plan */
         ndwt_mplan* mp = get_mplan(ndim, dims, names, dtype, cplx, l2, dilation, level, devices, ndev);
         rc = inverse ? ndwt_mrec_host(mp, mxGetData(x), mxGetData(plhs[0]), level) : ndwt_mdec_host(mp, mxGetData(x), mxGetData(plhs[0]), level);
 #if !MX_HAS_INTERLEAVED_COMPLEX

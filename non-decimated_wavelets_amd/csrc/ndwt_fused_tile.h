@@ -36,7 +36,8 @@ constexpr int kInv3YTX = 64, kInv3YTY = 32;
 // two register sets of band loads (staggered refill) fit the 128 registers of the 1024-thread workgroup without spills for 2, 8 and
 // 10 taps as they are, and for 12 taps with 6 of the 12 pending z sums in LDS (Inv3Y::ZLDS): 512^3 db6 1.37 -> 1.30 ms per launch.
 // (4 and 6 taps fit the same way -- 2 / 4 sums in LDS -- and run SLOWER than one register set: 1.05 vs 1.02, 1.18 vs 1.08 ms.)
-constexpr int inv3y_zlds(int L, int depth, int ew = 1) { return (depth == 2 && ew == 1 && L == 12) ? 6 : 0; }
+// 18 and 20 taps (one register set): 8 of the pending z sums in LDS -- without them the instances spill 7 .. 19 registers.
+constexpr int inv3y_zlds(int L, int depth, int ew = 1) { return ew != 1 ? 0 : (depth == 2 && L == 12) ? 6 : (L >= 18 ? 8 : 0); }
 constexpr int inv3y_ty(int L, int ew = 1) { return ew == 2 ? kInv3YTY : (L <= 16 ? kInv3YTY : (L <= 18 ? 24 : 28)); }
 constexpr int inv3y_tx(int L, int ew = 1) { return ew == 2 ? (L <= 10 ? kInv3YTX : 48) : (L <= 18 ? kInv3YTX : 48); }
 }  // namespace ndwt

@@ -22,4 +22,5 @@ mxArray* mxGetCell(const mxArray*, mwSize index);
 void* mxGetData(const mxArray*);
 void* mxGetImagData(const mxArray*);
 mxArray* mxCreateNumericArray(mwSize ndim, const mwSize* dims, mxClassID cls, mxComplexity flag);
+mxArray* mxCreateUninitNumericArray(mwSize ndim, mwSize* dims, mxClassID cls, mxComplexity flag);   /* R2015a+ */
 #endif

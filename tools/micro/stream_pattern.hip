@@ -114,6 +114,44 @@ template <bool NT_LD, bool NT_ST, int TY = 16> __global__ void __launch_bounds__
     }
 }
 
+
+// the same 8 -> 1 tile pattern fed by LDS-DMA (global_load_lds_dwordx4: no VGPR destination): two planes of all 8 bands in an LDS
+// ring (2 x 64 KiB), every wave loads its rows of the plane after next while the workgroup sums the current one from LDS.  The
+// bounded experiment of VERDICT r2 item 6: does a loader path that keeps the compute waves out of the vector-memory pipe's return
+// path beat the register path (fan_in_tiled) on this footprint?
+__global__ void __launch_bounds__(512) fan_in_tiled_dma(Bands in, float* out, int zchunk) {
+    extern __shared__ float ring[];                       // [2 planes][8 bands][512 chunks of 16 B]
+    int zbeg;
+    const long long off = tile_base<32, 512>(zbeg, zchunk);
+    const long long P = (long long)N * N;
+    const int zend = zbeg + zchunk;
+    const int wave = threadIdx.x / 64;
+    auto issue = [&](int z, int slot) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            // LDS destination: wave-uniform base + lane * 16: chunk index = thread index, band-major
+            float* dst = ring + ((slot * 8 + b) * 512 + wave * 64) * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in.p[b] + off + z * P),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+    issue(zbeg, 0);
+    if (zbeg + 1 < zend) issue(zbeg + 1, 1);
+    for (int z = zbeg; z < zend; ++z) {
+        const int slot = (z - zbeg) & 1;
+        // the loads of plane z are the older group of the two in flight (this wave's own 8; every wave waits for its own rows only:
+        // each thread reads back exactly the chunks its own wave loaded, so no barrier is needed)
+        if (z + 1 < zend) __builtin_amdgcn_s_waitcnt(0x0F70 | 8 | ((8 >> 4) << 14));   // vmcnt(8)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                                        // vmcnt(0)
+        v4 s = *(const v4*)(ring + ((slot * 8 + 0) * 512 + threadIdx.x) * 4);
+#pragma unroll
+        for (int b = 1; b < 8; ++b) s += *(const v4*)(ring + ((slot * 8 + b) * 512 + threadIdx.x) * 4);
+        st<true>(out + off + z * P, s);
+        __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0): the LDS reads are done before the slot is refilled
+        if (z + 2 < zend) issue(z + 2, slot);
+    }
+}
+
 // planes per workgroup so that `blocks` workgroups of 64 x TY tiles cover the volume exactly (anything else would run off the arrays)
 static int checked_zchunk(int blocks, int ty) {
     const int tiles = (N / 64) * (N / ty);
@@ -141,6 +179,7 @@ int main() {
     CK(hipFuncSetAttribute((const void*)fan_in_tiled<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     CK(hipFuncSetAttribute((const void*)fan_in_tiled<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     CK(hipFuncSetAttribute((const void*)fan_in_tiled<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    CK(hipFuncSetAttribute((const void*)fan_in_tiled_dma, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     float *coef = nullptr, *vol = nullptr;
     const long long pad = 64;
     CK(hipMalloc(&coef, (size_t)(8 * (VOL + pad)) * 4));
@@ -170,6 +209,8 @@ int main() {
         printf("fan-in  8->1 tiled   %s %.3f ms  %.0f GB/s  (nontemporal loads)\n", lay, t, gb / t * 1e3);
         t = time_ms([&] { hipLaunchKernelGGL((fan_in_tiled<true, true>), dim3(256), dim3(512), 96 * 1024, 0, b, vol, checked_zchunk(256, 32)); });
         printf("fan-in  8->1 tiled   %s %.3f ms  %.0f GB/s  (nontemporal loads and stores)\n", lay, t, gb / t * 1e3);
+        t = time_ms([&] { hipLaunchKernelGGL(fan_in_tiled_dma, dim3(256), dim3(512), 128 * 1024, 0, b, vol, checked_zchunk(256, 32)); });
+        printf("fan-in  8->1 tiled   %s %.3f ms  %.0f GB/s  (LDS-DMA ring of 2 planes, nontemporal stores)\n", lay, t, gb / t * 1e3);
         t = time_ms([&] { hipLaunchKernelGGL(fan_out_linear, dim3(256 * 8), dim3(256), 0, 0, vol, b); });
         printf("fan-out 1->8 linear  %s %.3f ms  %.0f GB/s\n", lay, t, gb / t * 1e3);
         t = time_ms([&] { hipLaunchKernelGGL((fan_out_tiled<false, false>), dim3(512), dim3(256), 0, 0, vol, b, checked_zchunk(512, 16)); });
