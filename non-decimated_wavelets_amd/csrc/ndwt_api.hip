@@ -410,9 +410,14 @@ template <typename T> static int nt_store_ok(long long rs, long long plane, long
 // one fused 3-D launch over `nbatch` volumes. n3 = output planes; z_wrap=false: inputs carry the z halo
 template <typename T>
 static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* in, T* const* out, long long n3, long long nbatch,
-                      long long in_bstride, long long out_bstride, int z_mode, hipStream_t s, long long zlo = 0, long long zhi = LLONG_MIN, long long zbs = 0, int shrink_mask = 0, int dil = 1) {
+                      long long in_bstride, long long out_bstride, int z_mode, hipStream_t s, long long zlo = 0, long long zhi = LLONG_MIN, long long zbs = 0, int shrink_mask = 0, int dil = 1,
+                      const double* ttaps = nullptr) {
     Fused3Args<T> a;
     memset(&a, 0, sizeof a);
+    if (ttaps) {                                          // 4-D analysis, t axis folded in: taps of this launch's t-band, frames = batch items
+        for (int j = 0; j < Lp; ++j) a.tt[j] = (T)ttaps[j];
+        a.bfast = 1;
+    }
     a.zlo = (int)zlo;                                     // mode 3: input planes outside [zlo, zhi) read as zero
     a.zhi = (int)(zhi != LLONG_MIN ? zhi : n3 - (Lp - 1));
     a.zbs = (int)zbs;
@@ -454,6 +459,7 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     if (!inverse && sizeof(T) == 4 && ew == 1 && variant == 0 && Lp >= 6 && Lp <= 8 &&
         (long long)((a.n1 + 63) / 64) * ((a.n2 + 31) / 32) * a.nbatch >= 32)
         variant = 2;
+    if (ttaps) variant = 6;                               // the folded t axis runs on the tall tile with y items of 2 rows
     // double analysis, 6 and 8 taps: 64x16 tile with 512 threads, one column per thread (384^3 db4: 1.29 -> 0.97 ms per launch,
     // 320^3 -15 %, 512^3 -2 %, 256^3 +2 %); NDWT_VARIANT_FWD=3 keeps the 64x8 tile with 256 threads
     if (!inverse && sizeof(T) == 8 && ew == 1 && variant == 0 && Lp >= 6 && Lp <= 8) variant = 1;
@@ -498,6 +504,13 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
         }
     }
     if constexpr (sizeof(T) == 4) {
+        if (ttaps) {
+            rc = vec4 ? launch_fwd3_tpre_f32(a, Lp, td, s) : -1;
+            if (rc == -1) {
+                prof_end(p, s, rc);
+                return fail(NDWT_ERR_UNSUPPORTED, "internal: no folded-t analysis kernel for tap length %d / this alignment", Lp);
+            }
+        }
         if (rc == -1 && Lp > 12 && ew == 1) rc = launch_long3_f32(inverse, a, t, vec4, variant, td, s);
     }
     if (rc == -1) rc = launch3<T>(inverse, a, t, vec4, ew != 1 ? (cplx_tall ? 2 : 0) : variant, ew, td, s);
@@ -579,7 +592,27 @@ static int analysis_level(ndwt_plan* p, const T* in, T* const* out, long long st
             const T* ins[8] = {in};
             return fused3_run<T>(p, false, Lp, ins, out, p->dims[2], 1, vol_in, p->vol, slab ? 0 : 1, s);
         }
-        // d == 4: outer axis per-axis (1 -> 2), then the fused 3-D kernel on both halves, batched over n4
+        // A/B variant 7 (Plan.set_variant(fwd=7)) -- MEASURED AND NOT THE DEFAULT: the t axis folded into the fused launches, each raw plane a
+        // workgroup takes being the t-filtered combination of the same plane of L frames (read where the neighbouring frames' workgroups
+        // read them: L2), one launch per t-band: 17 volume transfers per level instead of 21 (nd_dwt_4D.m:394-467).  The bytes go down,
+        // the time goes up: cfg5 (256^3 x 32, db4) 6.55 ms per launch against 3.41 ms + half of the 1.36 ms t pass -- the 8 loads per lane
+        // and plane (against 1) go through the same per-CU vector-memory pipe as the 4 stores, and that pipe is what bounds the kernel
+        // (68.6 ms per dec+rec step against 53.5 ms).
+        if constexpr (sizeof(T) == 4) {
+            bool ok = p->variant_fwd == 7 && !slab && stride == 1 && p->complexity == NDWT_REAL && Lp <= 8 && ftop.len <= Lp && p->dims[0] % 4 == 0 &&
+                      vol3 % 4 == 0 && p->dims[3] >= 2 && aligned_vec4<T>(in);
+            for (int b = 0; ok && b < 16; ++b) ok = aligned_vec4<T>(out[b]);
+            if (ok) {
+                double tlo[kMaxTaps], thi[kMaxTaps];
+                pad_taps(ftop.ana_lo, ftop.len, Lp, tlo);
+                pad_taps(ftop.ana_hi, ftop.len, Lp, thi);
+                const T* ins[8] = {in};
+                int rc = fused3_run<T>(p, false, Lp, ins, out, p->dims[2], p->dims[3], vol3, vol3, 1, s, 0, LLONG_MIN, 0, 0, 1, tlo);
+                if (rc) return rc;
+                return fused3_run<T>(p, false, Lp, ins, out + 8, p->dims[2], p->dims[3], vol3, vol3, 1, s, 0, LLONG_MIN, 0, 0, 1, thi);
+            }
+        }
+        // otherwise: outer axis per-axis (1 -> 2), then the fused 3-D kernel on both halves, batched over n4
         const long long skew = 256 / (long long)sizeof(T);   // the two halves 256 B off a power-of-two distance (see ndwt_band_pitch)
         int rc = ensure_tmp(p, (size_t)(2 * p->vol + skew) * sizeof(T));
         if (rc) return rc;

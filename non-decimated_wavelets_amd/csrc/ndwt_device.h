@@ -229,6 +229,12 @@ template <typename T> struct Fused3Args {
     int shrink_mask, shrink_hard;
     int nt;                // nontemporal output stores (float data whose rows are whole 128-byte lines)
     long long* stamps;     // diagnostic builds (-DNDWT_STAMPS) only: per wave, cycles spent in each phase of the plane loop
+    // 4-D analysis with the t axis folded into the launch (Fwd3<.., TPRE>): the batch items are the frames of a periodic t axis and
+    // every raw plane is the t-filtered combination, with these taps (the low- or the high-pass ones, zero-padded to L like the
+    // others), of the same plane of the frames t - (L/2-1) .. t + L/2 -- read where the neighbouring frames' workgroups have just
+    // read them (bfast: the frame index runs fastest in the block order, so those workgroups share an XCD's L2)
+    T tt[kMaxTaps];
+    int bfast;
 };
 
 // XCD-aware block order: hardware deals workgroups round-robin over the 8 XCDs (each with its own
@@ -267,12 +273,17 @@ template <typename T> NDWT_DEV TileCoord decode_tile(const Fused3Args<T>& a, int
     int nblocks = a.ntx * a.nty * a.nzc * a.nbatch;
     int lb = xcd_remap(bid, nblocks);
     TileCoord tc;
+    int fast_batch = 0;
+    if (a.bfast) {                                        // batch item fastest: the workgroups of one tile over all batch items are neighbours
+        fast_batch = lb % a.nbatch;
+        lb /= a.nbatch;
+    }
     int tx = lb % a.ntx;
     lb /= a.ntx;
     int ty = lb % a.nty;
     lb /= a.nty;
     int zc = lb % a.nzc;
-    tc.batch = lb / a.nzc;
+    tc.batch = a.bfast ? fast_batch : lb / a.nzc;
     tc.x0 = halo_l >= 0 ? tile_origin(tx, a.ntx, TX, a.n1, halo_l, halo_r) : tx * TX;
     tc.y0 = ty * TY;
     tc.zbeg = zc * a.zchunk;
@@ -347,9 +358,13 @@ template <int RSB> struct RowPair {
 // (re, im) pairs; the y and z stages are component-wise and do not change)
 // LOWONLY_: only band 0 (the approximation) is computed through and stored -- the analysis that feeds the deeper levels of a
 // denoising step whose finest level never materialises its detail bands (Den3)
-template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, int WPE_ = 2, int EW_ = 1, bool LOWONLY_ = false> struct Fwd3 {
+// TPRE_: the t axis of a 4-D level folded in (Fused3Args::tt): the raw plane of frame t is the t-filtered combination of L frames,
+// so a 4-D level needs no pass of its own over the data for the t axis (17 volume transfers instead of 21: the t pass wrote two
+// volumes and the fused launches read them back)
+template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, int WPE_ = 2, int EW_ = 1, bool LOWONLY_ = false, bool TPRE_ = false> struct Fwd3 {
     static constexpr int L = L_, TX = TX_, TY = TY_, NT = NT_, RY = RY_, EW = EW_;
-    static constexpr bool LOWONLY = LOWONLY_;
+    static constexpr bool LOWONLY = LOWONLY_, TPRE = TPRE_;
+    static_assert(!TPRE_ || VEC4_, "the folded t axis exists for rows of whole groups of 4 scalars");
     static constexpr bool VEC4 = VEC4_;
     static constexpr int NE = VEC4 ? 1 : 4;              // offsets kept per column
     static constexpr int WPE = WPE_;                     // waves per SIMD the register budget is sized for
@@ -383,8 +398,10 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
     struct State {
         v4 win[NCOL][L];     // raw samples of the last L planes, rotating
         v4 nxt[NCOL];        // prefetched plane
+        v4 tfr[TPRE ? L : 1][NCOL];   // TPRE: the prefetched plane of the L frames under the t filter
         int off[NCOL][NE];
     };
+    struct TFrames { long long off[L]; };                // TPRE: element offsets of the L frames under the t filter of this workgroup's frame
 
     static NDWT_DEV void setup(State& st, const Args& a, const TileCoord& tc, int tid) {
         NDWT_SFOR(k, NCOL)
@@ -396,6 +413,26 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
             NDWT_SFOR(e, NE)
                 st.off[k][e] = y * a.rs + modn(xb + e, a.n1);
             NDWT_SEND
+        NDWT_SEND
+    }
+
+    // TPRE: issue the loads of plane zraw of the L frames; tcombine() turns them into the t-filtered raw plane when it is consumed
+    static NDWT_DEV void load_frames(State& st, const Args& a, const TFrames& tf, int zraw) {
+        const long long zm = (long long)modn(zraw, a.n3);
+        NDWT_SFOR(j, (TPRE ? L : 0))
+            const T* p = a.in[0] + tf.off[j] + zm * a.plane;
+            NDWT_SFOR(k, NCOL)
+                st.tfr[j][k] = *reinterpret_cast<const v4*>(p + st.off[k][0]);
+            NDWT_SEND
+        NDWT_SEND
+    }
+    static NDWT_DEV void tcombine(State& st, const Args& a) {
+        NDWT_SFOR(k, NCOL)
+            v4 acc = (v4)(T(0));
+            NDWT_SFOR(j, (TPRE ? L : 0))
+                acc += a.tt[j] * st.tfr[j][k];
+            NDWT_SEND
+            st.nxt[k] = acc;
         NDWT_SEND
     }
 
@@ -580,18 +617,39 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
         const TileCoord tc = decode_tile(a, bid, TX, TY, VEC4 ? -1 : 4 * GL, 4 * GR);
         const T* inb = a.in[0] + batch_base(tc.batch, a.bsplit, a.in_bstride, a.in_bstride2);
         const long long obase = batch_base(tc.batch, a.bsplit, a.out_bstride, a.out_bstride2);
+        TFrames tf;
+        if constexpr (TPRE) {                             // frames t - LH .. t + RH of the periodic t axis (the batch index)
+            NDWT_SFOR(j, L)
+                tf.off[j] = (long long)modn(tc.batch - LH + j, a.nbatch) * a.in_bstride;
+            NDWT_SEND
+        }
+        auto fetch = [&](State& st, int zraw) __attribute__((always_inline)) {
+            if constexpr (TPRE) load_frames(st, a, tf, zraw);
+            else load_plane(st, a, inb, zraw);
+        };
         // planes zbeg-LH .. zbeg-LH+L-2 into slots 0..L-2, then prefetch the plane of step 0
         ex.each([&](int tid, State& st) __attribute__((always_inline)) {
             setup(st, a, tc, tid);
-            prologue(st, a, inb, tc.zbeg);
-            load_plane(st, a, inb, tc.zbeg + RH);
+            if constexpr (TPRE) {
+                NDWT_SFOR(j, L - 1)
+                    load_frames(st, a, tf, tc.zbeg - LH + j);
+                    tcombine(st, a);
+                    NDWT_SFOR(k, NCOL)
+                        st.win[k][j] = st.nxt[k];
+                    NDWT_SEND
+                NDWT_SEND
+            } else {
+                prologue(st, a, inb, tc.zbeg);
+            }
+            fetch(st, tc.zbeg + RH);
         });
         const int nsteps = tc.zend - tc.zbeg;
         for (int s = 0; s < nsteps; ++s) {
             const int z = tc.zbeg + s;
             ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+                if constexpr (TPRE) tcombine(st, a);                      // the prefetched frames -> the t-filtered raw plane
                 zdispatch<0>(s % L, st, sh, tp, tid);                     // consumes st.nxt
-                if (s + 1 < nsteps) load_plane(st, a, inb, z + 1 + RH);   // prefetch for the next step
+                if (s + 1 < nsteps) fetch(st, z + 1 + RH);                // prefetch for the next step
             });
             ex.barrier();
             NDWT_SETPRIO(1);                              // the stages that end in this plane's stores go ahead of the other

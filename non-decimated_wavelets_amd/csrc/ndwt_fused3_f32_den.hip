@@ -48,4 +48,24 @@ int launch_fwd3_low_f32(const Fused3Args<float>& a, int Lp, bool vec4, const voi
         default: return -1;
     }
 }
+
+// 4-D analysis with the t axis folded in (Fwd3<.., TPRE>): the tall tile with y items of 2 rows (Fused3Tile<float, false, 6>: the 8
+// prefetched frames fit its register budget), rows of whole groups of 4 scalars
+template <int LL> static int go_tpre(const Fused3Args<float>& a, const void* taps_dev, hipStream_t s) {
+    typedef Fused3Tile<float, false, 6> TL;
+    typedef Fwd3<float, LL, TL::TX, TL::TY, TL::NT, TL::RY, true, TL::WPE, 1, false, true> K;
+    FusedTapsD unused;
+    unused.Lp = LL;
+    return launch_fused3<K>(a, unused, taps_dev, s);
+}
+
+int launch_fwd3_tpre_f32(const Fused3Args<float>& a, int Lp, const void* taps_dev, hipStream_t s) {
+    switch (Lp) {
+        case 2: return go_tpre<2>(a, taps_dev, s);
+        case 4: return go_tpre<4>(a, taps_dev, s);
+        case 6: return go_tpre<6>(a, taps_dev, s);
+        case 8: return go_tpre<8>(a, taps_dev, s);
+        default: return -1;
+    }
+}
 }  // namespace ndwt

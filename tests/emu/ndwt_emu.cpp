@@ -476,6 +476,34 @@ extern "C" int ndwt_emu_den3_f32(int Lp, const float* x, const float* apx, float
         default: return -1;
     }
 }
+// one 4-D analysis level with the t axis folded into the fused launches (Fwd3<.., TPRE>): x (n4 frames) -> 16 bands
+template <int LL> static int run_tpre(ndwt::Fused3Args<float>& a, const double* lo, const double* hi) {
+    typedef ndwt::Fused3Tile<float, false, 6> TL;
+    return run<ndwt::Fwd3<float, LL, TL::TX, TL::TY, TL::NT, TL::RY, true, 2, 1, false, true>, float>(a, lo, hi);
+}
+extern "C" int ndwt_emu_tpre_f32(int Lp, const float* x, float* out, int n1, int n2, int n3, int n4, int zchunk, const double* alo,
+                                 const double* ahi, const double* tlo, const double* thi) {
+    const long long vol3 = (long long)n1 * n2 * n3;
+    for (int tb = 0; tb < 2; ++tb) {
+        ndwt::Fused3Args<float> a;
+        std::memset(&a, 0, sizeof(a));
+        a.n1 = n1; a.n2 = n2; a.n3 = n3; a.nbatch = n4; a.z_wrap = 1; a.bfast = 1;
+        a.in[0] = x;
+        a.in_bstride = a.out_bstride = vol3;
+        for (int b = 0; b < 8; ++b) a.out[b] = out + (long long)(8 * tb + b) * vol3 * n4;
+        for (int j = 0; j < Lp; ++j) a.tt[j] = (float)(tb ? thi[j] : tlo[j]);
+        ndwt::fused3_geometry(a, 64, 32, Lp, 4, zchunk);
+        int rc = -1;
+        switch (Lp) {
+            case 2: rc = run_tpre<2>(a, alo, ahi); break;
+            case 4: rc = run_tpre<4>(a, alo, ahi); break;
+            case 6: rc = run_tpre<6>(a, alo, ahi); break;
+            case 8: rc = run_tpre<8>(a, alo, ahi); break;
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}
 extern "C" int ndwt_emu_low3_f32(int Lp, int vec4, const float* x, float* out, int n1, int n2, int n3, int zchunk, const double* alo,
                                  const double* ahi) {
     ndwt::Fused3Args<float> a;

@@ -487,3 +487,25 @@ def test_emulated_approximation_only_analysis(emu, sizes, wname, vec4, zchunk):
     assert emu.ndwt_emu_low3_f32(L, int(vec4), p(xs), p(out), n1, n2, n3, zchunk, p(t["ana_lo"]), p(t["ana_hi"])) == 0
     got = np.transpose(out)
     assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("sizes,wname,zchunk", [((68, 36, 6, 5), "db4", 0), ((64, 32, 9, 3), "db2", 4), ((72, 33, 5, 9), "db1", 0)])
+def test_emulated_4d_analysis_with_folded_t_axis(emu, sizes, wname, zchunk):
+    """Fwd3<.., TPRE>: a 4-D analysis level in two launches (one per t-band) whose raw planes are the t-filtered combination of L
+    frames -- no pass of its own over the data for the t axis (reference: level_1_dec of nd_dwt_4D.m:394-467)"""
+    rng = np.random.default_rng(33)
+    x = rng.standard_normal(sizes)
+    filt = [orc.wave_filters(wname)] * 4
+    want = orc.spatial_level_dec(x, filt, 1)
+    L = len(filt[0][0])
+    t = _taps3(wname, 1, L)
+    tl, th = np.ascontiguousarray(t["ana_lo"][0]), np.ascontiguousarray(t["ana_hi"][0])
+    xs = to_kernel_order(x).astype(np.float32)
+    n4, n3, n2, n1 = xs.shape
+    out = np.full((16, n4, n3, n2, n1), np.nan, dtype=np.float32)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    assert emu.ndwt_emu_tpre_f32(L, p(xs), p(out), n1, n2, n3, n4, zchunk, p(t["ana_lo"]), p(t["ana_hi"]), p(tl), p(th)) == 0
+    got = np.transpose(out)
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()

@@ -1004,3 +1004,20 @@ def test_sharded_driver_band_pitch_option():
     assert torch.equal(a.rec(ya), b.rec(yb)) and yb.view(-1).numel() == yb.numel()
     with pytest.raises(ValueError, match="band_pitch"):
         sh.ShardedNdDwt("db4", [72, 40, 24], device=dev, band_pitch="odd")
+
+
+def test_4d_analysis_with_folded_t_axis_variant():
+    """A/B variant 7 of the 4-D analysis (the t axis folded into the fused launches, 17 instead of 21 volume transfers per level; measured
+    slower -- more loads through the vector-memory pipe -- and therefore not the default): the same coefficients as the default path"""
+    sizes = [64, 32, 12, 6]
+    rng = np.random.default_rng(71)
+    x = rng.standard_normal(sizes)
+    w = ndwt.nd_dwt_4D("db4", sizes, "pres_l2_norm", 1, "precision", "single")
+    xg = _colmajor_gpu(x, "single")
+    y0 = w.dec(xg, 2)
+    list(w._plans.values())[0].set_variant(fwd=7)
+    y7 = w.dec(xg, 2)
+    list(w._plans.values())[0].set_variant(fwd=0)
+    want = orc.spatial_dec(x, ["db4"] * 4, 2, 1)
+    assert _relerr(y7.cpu().numpy(), want) <= TOL["single"] and _relerr(y0.cpu().numpy(), want) <= TOL["single"]
+    assert float((y7 - y0).abs().max()) <= 2e-6 * float(y0.abs().max())
