@@ -94,13 +94,11 @@ NDWT_DEV float ndwt_sqrt(float v) { return __builtin_sqrtf(v); }
 NDWT_DEV double ndwt_sqrt(double v) { return __builtin_sqrt(v); }
 
 // soft / hard shrinkage of the 4 scalars one lane holds; EW = 2: two interleaved complex values, the magnitude shrinks
+template <typename T, class V4> NDWT_DEV void shrink4_flat(V4& c, T thr, int hard);
 template <typename T, int EW, class V4> NDWT_DEV void shrink4(V4& c, T thr, int hard) {
     if constexpr (EW == 1) {
-        NDWT_SFOR(e, 4)
-            const T v = c[e];
-            const T m = v < T(0) ? -v : v;
-            c[e] = m > thr ? (hard ? v : (v < T(0) ? v + thr : v - thr)) : T(0);
-        NDWT_SEND
+        // real data: m > thr ? (hard ? v : (v < 0 ? v + thr : v - thr)) : 0 without divergent branches (the same operations, the same bits)
+        shrink4_flat<T>(c, thr, hard);
     } else {
         NDWT_SFOR(h, 2)
             const T re = c[2 * h], im = c[2 * h + 1];

@@ -1009,7 +1009,7 @@ def test_sharded_driver_band_pitch_option():
 def test_4d_analysis_with_folded_t_axis_variant():
     """A/B variant 7 of the 4-D analysis (the t axis folded into the fused launches, 17 instead of 21 volume transfers per level; measured
     slower -- more loads through the vector-memory pipe -- and therefore not the default): the same coefficients as the default path"""
-    sizes = [64, 32, 12, 6]
+    sizes = [64, 32, 12, 9]
     rng = np.random.default_rng(71)
     x = rng.standard_normal(sizes)
     w = ndwt.nd_dwt_4D("db4", sizes, "pres_l2_norm", 1, "precision", "single")
