@@ -416,7 +416,6 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     memset(&a, 0, sizeof a);
     if (ttaps) {                                          // 4-D analysis, t axis folded in: taps of this launch's t-band, frames = batch items
         for (int j = 0; j < Lp; ++j) a.tt[j] = (T)ttaps[j];
-        a.bfast = 1;
     }
     a.zlo = (int)zlo;                                     // mode 3: input planes outside [zlo, zhi) read as zero
     a.zhi = (int)(zhi != LLONG_MIN ? zhi : n3 - (Lp - 1));

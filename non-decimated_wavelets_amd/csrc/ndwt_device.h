@@ -230,9 +230,8 @@ template <typename T> struct Fused3Args {
     // 4-D analysis with the t axis folded into the launch (Fwd3<.., TPRE>): the batch items are the frames of a periodic t axis and
     // every raw plane is the t-filtered combination, with these taps (the low- or the high-pass ones, zero-padded to L like the
     // others), of the same plane of the frames t - (L/2-1) .. t + L/2 -- read where the neighbouring frames' workgroups have just
-    // read them (bfast: the frame index runs fastest in the block order, so those workgroups share an XCD's L2)
+    // read them (the frame index runs fastest in that kernel's block order, so those workgroups share an XCD's L2)
     T tt[kMaxTaps];
-    int bfast;
 };
 
 // XCD-aware block order: hardware deals workgroups round-robin over the 8 XCDs (each with its own
@@ -267,12 +266,15 @@ NDWT_DEV int tile_origin(int t, int ntiles, int width, int n, int halo_l, int ha
     return (n % 4 != 0 && x0 + width + halo_r > n && xr >= halo_l) ? xr : x0;
 }
 
-template <typename T> NDWT_DEV TileCoord decode_tile(const Fused3Args<T>& a, int bid, int TX, int TY, int halo_l = -1, int halo_r = 0) {
+// BFAST (compile time: the extra division changes the register allocation of kernels that are a few registers from spilling): the batch
+// item runs fastest in the block order, so the workgroups of one tile over all batch items are neighbours on one XCD
+template <typename T, bool BFAST = false>
+NDWT_DEV TileCoord decode_tile(const Fused3Args<T>& a, int bid, int TX, int TY, int halo_l = -1, int halo_r = 0) {
     int nblocks = a.ntx * a.nty * a.nzc * a.nbatch;
     int lb = xcd_remap(bid, nblocks);
     TileCoord tc;
     int fast_batch = 0;
-    if (a.bfast) {                                        // batch item fastest: the workgroups of one tile over all batch items are neighbours
+    if constexpr (BFAST) {
         fast_batch = lb % a.nbatch;
         lb /= a.nbatch;
     }
@@ -281,7 +283,7 @@ template <typename T> NDWT_DEV TileCoord decode_tile(const Fused3Args<T>& a, int
     int ty = lb % a.nty;
     lb /= a.nty;
     int zc = lb % a.nzc;
-    tc.batch = a.bfast ? fast_batch : lb / a.nzc;
+    tc.batch = BFAST ? fast_batch : lb / a.nzc;
     tc.x0 = halo_l >= 0 ? tile_origin(tx, a.ntx, TX, a.n1, halo_l, halo_r) : tx * TX;
     tc.y0 = ty * TY;
     tc.zbeg = zc * a.zchunk;
@@ -612,7 +614,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
     }
 
     template <class Exec> static NDWT_DEV void block(Exec& ex, Shared& sh, const Args& a, const Taps& tp, int bid) {
-        const TileCoord tc = decode_tile(a, bid, TX, TY, VEC4 ? -1 : 4 * GL, 4 * GR);
+        const TileCoord tc = decode_tile<T, TPRE>(a, bid, TX, TY, VEC4 ? -1 : 4 * GL, 4 * GR);
         const T* inb = a.in[0] + batch_base(tc.batch, a.bsplit, a.in_bstride, a.in_bstride2);
         const long long obase = batch_base(tc.batch, a.bsplit, a.out_bstride, a.out_bstride2);
         TFrames tf;

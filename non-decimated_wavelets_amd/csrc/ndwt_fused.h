@@ -32,7 +32,7 @@ int launch_inv3yc_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, 
 // that goes with it (tall 64 x 32 tile); float, real data, tap lengths 2 .. 8: ndwt_fused3_f32_den.hip
 int launch_den3_f32(const Fused3Args<float>& a, int Lp, const void* taps_dev, hipStream_t s);
 int launch_fwd3_low_f32(const Fused3Args<float>& a, int Lp, bool vec4, const void* taps_dev, hipStream_t s);
-// one t-band of a 4-D analysis level with the t axis folded into the launch (a.tt = its t taps, batch items = frames, a.bfast)
+// one t-band of a 4-D analysis level with the t axis folded into the launch (a.tt = its t taps, batch items = frames, frame index fastest in the block order)
 int launch_fwd3_tpre_f32(const Fused3Args<float>& a, int Lp, const void* taps_dev, hipStream_t s);
 
 // float, tap lengths 14..18 (analysis) / 14..16 (synthesis): ndwt_fused3_f32_long.hip

@@ -487,7 +487,7 @@ extern "C" int ndwt_emu_tpre_f32(int Lp, const float* x, float* out, int n1, int
     for (int tb = 0; tb < 2; ++tb) {
         ndwt::Fused3Args<float> a;
         std::memset(&a, 0, sizeof(a));
-        a.n1 = n1; a.n2 = n2; a.n3 = n3; a.nbatch = n4; a.z_wrap = 1; a.bfast = 1;
+        a.n1 = n1; a.n2 = n2; a.n3 = n3; a.nbatch = n4; a.z_wrap = 1;
         a.in[0] = x;
         a.in_bstride = a.out_bstride = vol3;
         for (int b = 0; b < 8; ++b) a.out[b] = out + (long long)(8 * tb + b) * vol3 * n4;

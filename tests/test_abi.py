@@ -115,3 +115,51 @@ def test_mex_shim_syntax_against_declaration_stubs():
                             "-I", os.path.join(root, "include")] + extra + [os.path.join(root, "matlab", "nd_dwt_hip_mex.c")],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_headline_kernels_do_not_spill():
+    """A register spill inside a plane loop waits for every load in flight (vmcnt(0)): the kernels of the BASELINE configurations must
+    keep their state in registers.  Reads the resource notes of the built objects (csrc/build/*.o); skipped before the first build."""
+    import glob
+    import re
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    objs = sorted(glob.glob(os.path.join(ROOT, "non-decimated_wavelets_amd", "csrc", "build", "*.o")))
+    if not objs or not os.path.exists(os.path.join(llvm, "clang-offload-bundler")):
+        pytest.skip("no built objects / no ROCm llvm tools")
+    spills = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for o in objs:
+            b = os.path.join(tmp, os.path.basename(o))
+            if subprocess.run([f"{llvm}/llvm-objcopy", f"--dump-section=.hip_fatbin={b}.fat", o], capture_output=True).returncode:
+                continue
+            if subprocess.run([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                               f"--input={b}.fat", f"--output={b}.elf"], capture_output=True).returncode:
+                continue
+            notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", f"{b}.elf"], capture_output=True, text=True).stdout
+            name = None
+            for line in notes.splitlines():
+                m = re.match(r"\s+\.name:\s+(\S+)", line)
+                if m:
+                    name = m.group(1)
+                m = re.match(r"\s+\.vgpr_spill_count:\s+(\d+)", line)
+                if m and name:
+                    spills[name] = int(m.group(1))
+    assert len(spills) > 100
+    # mangled fragments: kernel struct, float, tap length, tile / threads, VEC4 (b1 / b0), ...
+    must_not_spill = [
+        "Inv3YIfLi8ELi64ELi32ELi1024ELb1ELi4ELi2",      # cfg3 / cfg5 synthesis: two register sets
+        "Inv3YIfLi8ELi64ELi32ELi1024ELb0ELi4ELi2",      # the same on rows that are not whole groups of 4 scalars
+        "Inv3YIfLi12ELi64ELi32ELi1024ELb1ELi4ELi2",     # cfg4 (db6) synthesis: two register sets, 6 z sums in LDS
+        "Fwd3IfLi8ELi64ELi32ELi1024ELi4ELb1",           # cfg3 / cfg5 analysis, tall tile
+        "Fwd3IfLi12ELi64ELi32ELi1024ELi2ELb1",          # cfg4 analysis
+        "Fwd2SIfLi8ELb1", "Inv2SIfLi8ELb1",             # cfg2
+        "Den3IfLi2E", "Den3IfLi4E", "Den3IfLi6E", "Den3IfLi8E",
+        "Inv3YIfLi18E", "Inv3YIfLi20E",
+    ]
+    for frag in must_not_spill:
+        hit = {k: v for k, v in spills.items() if frag in k and "ELb0ELb1EEE" not in k}      # (not the folded-t A/B variant)
+        assert hit, frag
+        bad = {k: v for k, v in hit.items() if v and not (frag.startswith("Inv3YIfLi1") and "ELb0ELi4E" in k)}
+        assert not bad, bad
