@@ -557,13 +557,27 @@ static int fused2_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     for (int b = 0; b < nin; ++b) { a.in[b] = in[b]; vec4 = vec4 && aligned_vec4<T>(in[b]); }
     for (int b = 0; b < nout; ++b) { a.out[b] = out[b]; vec4 = vec4 && aligned_vec4<T>(out[b]); }
     const int ew2 = dil > 1 ? dil : (int)p->comp;
-    fused2_geometry(a, fused2_tile_width(inverse, Lp, ew2), Lp, p->target_blocks > 0 ? p->target_blocks * 2 : 2048, p->force_zchunk);
+    // float synthesis of real data in rows of whole groups of 4 scalars, images whose 70-row chunks fit one round of 1024 waves (up to
+    // 4096^2): Inv2P -- 4 rows of band loads in flight per wave, the row loop unrolled in groups of L so that the compiler waits for
+    // exactly the load a row needs, half as many waves on chunks twice as long (the L-1 prologue rows of a chunk are re-read).  Interleaved
+    // A/B, 3 levels of rec: 1024^2 52 -> 43 us, 2048^2 81 -> 80, 4096^2 289 -> 265; 8192^2 927 -> 961 (not taken there: the run needs
+    // more than one round of waves either way).  variant_inv: 1 keeps Inv2S, 2 / 4 = depth on Inv2S's geometry, 6 = depth 2 on 1024 waves.
+    const int tiles2 = (a.n1 + fused2_tile_width(inverse, Lp, ew2) - 1) / fused2_tile_width(inverse, Lp, ew2);
+    const bool deep = inverse && sizeof(T) == 4 && ew2 == 1 && dil == 1 && vec4 && p->variant_inv != 1 && n2 >= 64 &&
+                      ((long long)tiles2 * ((n2 + 69) / 70) <= 1280 || p->variant_inv >= 2);
+    const int pdepth = (p->variant_inv == 2 || p->variant_inv == 6) ? 2 : 4;
+    const int waves = (deep && p->variant_inv != 2 && p->variant_inv != 4) ? 1024 : 2048;
+    fused2_geometry(a, fused2_tile_width(inverse, Lp, ew2), Lp, p->target_blocks > 0 ? p->target_blocks * 2 : waves, p->force_zchunk);
     if (dil > 1) a.rs = (int)(dil * p->dims[0]);   // 8 waves per CU: one round (measured optimum 1024^2 .. 4096^2)
     a.nt = nt_store_ok<T>(a.rs, a.rs, out_bstride, out, nout);
     const void* td = p->taps_dev[inverse ? 1 : 0];
     if (!td) return fail(NDWT_ERR_UNSUPPORTED, "plan has no device tap table");
     prof_begin(p, inverse ? NDWT_KERNEL_FUSED_SYNTHESIS : NDWT_KERNEL_FUSED_ANALYSIS, s);
-    int rc = launch2<T>(inverse, a, Lp, vec4, ew2, td, s);
+    int rc = -1;
+    if constexpr (sizeof(T) == 4) {
+        if (deep) rc = launch_inv2p_f32(a, Lp, pdepth, td, s);
+    }
+    if (rc == -1) rc = launch2<T>(inverse, a, Lp, vec4, ew2, td, s);
     prof_end(p, s, rc);
     if (rc == -1) return fail(NDWT_ERR_UNSUPPORTED, "no fused 2-D kernel instantiated for tap length %d", Lp);
     if (rc != 0) return fail(NDWT_ERR_HIP, "fused 2-D kernel launch failed: %s", hipGetErrorString((hipError_t)rc));

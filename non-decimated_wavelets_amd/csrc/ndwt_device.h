@@ -2263,6 +2263,117 @@ template <typename T, int L_, bool VEC4_, int WPE_ = 4, int EW_ = 1> struct Inv2
     }
 };
 
+// The same 2-D synthesis with PD rows of band loads in flight per wave and the row loop UNROLLED IN GROUPS OF L, so that the rotation of
+// the y sums and the slot of every row are compile-time constants in straight-line code.  Inv2S issues the loads of row p+1 after it has
+// consumed row p and dispatches on p % L at run time: hipcc's wait-count insertion cannot follow loads across that dispatch and waits
+// vmcnt(0) at the first use, so a wave exposes one full memory latency per row and the kernel needs 8 waves per CU on chunks so short that
+// the L-1 prologue rows re-read 20 % of every chunk (FETCH_SIZE 1.40x the bands at 4096^2).  Here the compiler sees which load feeds which
+// row and waits for exactly that one.  Float / double real data in rows of whole groups of 4 scalars; everything else keeps Inv2S.
+template <typename T, int L_, int PD_ = 2, int WPE_ = 2> struct Inv2P {
+    static constexpr int L = L_, NT = 64, WPE = WPE_, PD = PD_;
+    static_assert(L % PD == 0, "the depth divides the tap length: a row's slot is p % PD with p = group base + k");
+    static constexpr int LH = L / 2, RH = L / 2 - 1;
+    static constexpr int GL = (LH + 3) / 4, GR = (RH + 3) / 4;
+    static constexpr int WX = 4 * (64 - GL - GR);
+    static constexpr int XV = 4 * (1 + GL + GR);
+    typedef typename VecT<T>::v4 v4;
+    typedef Taps3<T, L> Taps;
+    typedef Fused2Args<T> Args;
+    struct Shared { int unused; };
+    struct State {
+        T yacc[L][4];      // y-synthesis in scatter form: partial sums of the next L output rows (4 x each)
+        v4 raw[PD][4];     // 4 x of every band of the rows in flight: row p in slot p % PD
+        int off;
+    };
+    template <int S> static NDWT_DEV void load_row(State& st, const Args& a, long long ibase, int yraw) {
+        const long long ym = a.y_wrap ? (long long)modn(yraw, a.n2) : (long long)(yraw + LH);
+        NDWT_SFOR(b, 4)
+            st.raw[S][b] = *reinterpret_cast<const v4*>(a.in[b] + ibase + ym * a.rs + st.off);
+        NDWT_SEND
+    }
+    template <int S> static NDWT_DEV void pre(State& st, const Args& a) {
+        if (a.shrink_mask) {
+            NDWT_SFOR(b, 4)
+                if ((a.shrink_mask >> b) & 1) shrink4<T, 1>(st.raw[S][b], a.shrink_thr, a.shrink_hard);
+            NDWT_SEND
+        }
+    }
+    // row p = group base + K (rotation R = (K + 1) % L, slot K % PD): x-synthesis via lane shifts, y-synthesis in scatter form
+    template <int K, class Exec>
+    static NDWT_DEV void step(Exec& ex, State& st, const Taps& tp, const Args& a, const Tile2Coord& tc, long long obase, int y, bool emit, int tid) {
+        constexpr int R = (K + 1) % L, S = K % PD;
+        T p0[4], p1[4];
+        NDWT_SFOR(e, 4)
+            p0[e] = T(0);
+            p1[e] = T(0);
+        NDWT_SEND
+        NDWT_SFOR(i, XV)
+            constexpr int D = i / 4 - GL;
+            constexpr int c = i % 4;
+            {
+                const T wa0 = NDWT_LANE_SHIFT(ex, tid, D, s.raw[S][0][c]);
+                const T wd0 = NDWT_LANE_SHIFT(ex, tid, D, s.raw[S][1][c]);
+                const T wa1 = NDWT_LANE_SHIFT(ex, tid, D, s.raw[S][2][c]);
+                const T wd1 = NDWT_LANE_SHIFT(ex, tid, D, s.raw[S][3][c]);
+                NDWT_SFOR(e, 4)
+                    constexpr int j = i - 4 * GL - e + LH;
+                    if constexpr (j >= 0 && j < L) {
+                        p0[e] += tp.lo[0][j] * wa0;
+                        p0[e] += tp.hi[0][j] * wd0;
+                        p1[e] += tp.lo[0][j] * wa1;
+                        p1[e] += tp.hi[0][j] * wd1;
+                    }
+                NDWT_SEND
+            }
+        NDWT_SEND
+        NDWT_SFOR(j, L)
+            constexpr int slot = ((R - 1 - j) % L + L) % L;
+            NDWT_SFOR(e, 4)
+                const T c = tp.lo[1][j] * p0[e] + tp.hi[1][j] * p1[e];
+                if constexpr (j == 0) st.yacc[slot][e] = c;
+                else st.yacc[slot][e] += c;
+            NDWT_SEND
+        NDWT_SEND
+        if (!emit) return;
+        constexpr int done = ((R - L) % L + L) % L;
+        const int gx = tc.x0 + 4 * (tid - GL);
+        if (tid < GL || tid >= 64 - GR || gx >= a.n1) return;
+        stream_store(reinterpret_cast<v4*>(a.out[0] + obase + (long long)y * a.rs + gx),
+                     v4{st.yacc[done][0], st.yacc[done][1], st.yacc[done][2], st.yacc[done][3]}, a.nt);
+    }
+    // one row of a group: threshold, consume, refill the slot with row p + PD (separate passes: neighbouring lanes read this lane's registers)
+    template <int K, class Exec>
+    static NDWT_DEV void row(Exec& ex, const Taps& tp, const Args& a, const Tile2Coord& tc, long long ibase, long long obase, int p, int nrows) {
+        const int s = p - (L - 1);
+        ex.each([&](int, State& st) __attribute__((always_inline)) { pre<K % PD>(st, a); });
+        ex.each([&](int tid, State& st) __attribute__((always_inline)) { step<K>(ex, st, tp, a, tc, obase, tc.ybeg + s, s >= 0, tid); });
+        ex.each([&](int, State& st) __attribute__((always_inline)) {
+            if (p + PD < nrows) load_row<K % PD>(st, a, ibase, tc.ybeg - LH + p + PD);
+        });
+    }
+    template <class Exec> static NDWT_DEV void block(Exec& ex, Shared&, const Args& a, const Taps& tp, int bid) {
+        const Tile2Coord tc = decode_tile2(a, bid, WX);
+        const long long ibase = (long long)tc.batch * a.in_bstride;
+        const long long obase = (long long)tc.batch * a.out_bstride;
+        const int nrows = tc.yend - tc.ybeg + L - 1;
+        ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+            st.off = modn(tc.x0 - 4 * GL + 4 * tid, a.n1);
+            NDWT_SFOR(q, PD)
+                if (q < nrows) load_row<q>(st, a, ibase, tc.ybeg - LH + q);
+            NDWT_SEND
+        });
+        int p = 0;
+        for (; p + L <= nrows; p += L) {                  // whole groups: straight-line code, no test per row
+            NDWT_SFOR(k, L)
+                row<k>(ex, tp, a, tc, ibase, obase, p + k, nrows);
+            NDWT_SEND
+        }
+        NDWT_SFOR(k, L - 1)                               // the last, partial group
+            if (p + k < nrows) row<k>(ex, tp, a, tc, ibase, obase, p + k, nrows);
+        NDWT_SEND
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // One non-contiguous axis per launch, marched with the filter window in registers (no LDS, no halo re-reads):
 // 1 read -> 2 writes (analysis) / 2 reads -> 1 write (synthesis, scatter form).  The array is [outer][N][inner];

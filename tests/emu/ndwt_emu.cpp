@@ -504,6 +504,31 @@ extern "C" int ndwt_emu_tpre_f32(int Lp, const float* x, float* out, int n1, int
     }
     return 0;
 }
+// 2-D float synthesis with PD rows of band loads in flight per wave, row loop unrolled in groups of L (Inv2P)
+template <int LL, int PD> static int run_inv2p(ndwt::Fused2Args<float>& a, const double* lo, const double* hi, int ychunk) {
+    typedef ndwt::Inv2P<float, LL, PD, 2> K;
+    ndwt::fused2_geometry(a, K::WX, LL, 64, ychunk);
+    return run2<K, float>(a, lo, hi);
+}
+extern "C" int ndwt_emu2_inv2p_f32(int Lp, int depth, const float* in, float* out, int n1, int n2, int ychunk, const double* lo, const double* hi,
+                                   double shrink_thr, int shrink_mask, int shrink_hard) {
+    ndwt::Fused2Args<float> a;
+    std::memset(&a, 0, sizeof(a));
+    a.n1 = n1; a.n2 = n2; a.nbatch = 1; a.y_wrap = 1;
+    a.shrink_thr = (float)shrink_thr; a.shrink_mask = shrink_mask; a.shrink_hard = shrink_hard;
+    const long long vol = (long long)n1 * n2;
+    a.in_bstride = a.out_bstride = vol;
+    for (int b = 0; b < 4; ++b) a.in[b] = in + b * vol;
+    a.out[0] = out;
+    switch (Lp) {
+        case 2: return run_inv2p<2, 2>(a, lo, hi, ychunk);
+        case 4: return depth == 4 ? run_inv2p<4, 4>(a, lo, hi, ychunk) : run_inv2p<4, 2>(a, lo, hi, ychunk);
+        case 6: return run_inv2p<6, 2>(a, lo, hi, ychunk);
+        case 8: return depth == 4 ? run_inv2p<8, 4>(a, lo, hi, ychunk) : run_inv2p<8, 2>(a, lo, hi, ychunk);
+        case 12: return depth == 4 ? run_inv2p<12, 4>(a, lo, hi, ychunk) : run_inv2p<12, 2>(a, lo, hi, ychunk);
+        default: return -1;
+    }
+}
 extern "C" int ndwt_emu_low3_f32(int Lp, int vec4, const float* x, float* out, int n1, int n2, int n3, int zchunk, const double* alo,
                                  const double* ahi) {
     ndwt::Fused3Args<float> a;

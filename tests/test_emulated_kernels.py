@@ -509,3 +509,29 @@ def test_emulated_4d_analysis_with_folded_t_axis(emu, sizes, wname, zchunk):
     got = np.transpose(out)
     assert np.isfinite(got).all()
     assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("sizes,wname,ychunk,shrink", [((256, 21), "db4", 0, None), ((500, 13), "db4", 5, (0.4, 0xE, 0)), ((252, 9), "db3", 0, None),
+                                                        ((248, 30), "db6", 11, (0.3, 0xE, 1)), ((40, 6), "db1", 2, None), ((260, 4), "db2", 0, None)])
+@pytest.mark.parametrize("depth", [2, 4])
+def test_emulated_fused2_synthesis_with_rows_in_flight(emu, sizes, wname, ychunk, shrink, depth):
+    """Inv2P: 2 or 4 rows of band loads in flight per wave, the row loop unrolled in groups of L (rotation and slot of every row compile-time
+    constants), including chunks shorter than a group and the thresholding of the row about to be consumed"""
+    rng = np.random.default_rng(34)
+    c = rng.standard_normal(tuple(sizes) + (4,))
+    filt = [orc.wave_filters(wname)] * 2
+    cs = _np_shrink_bands(c, shrink[0], shrink[2], shrink[1]) if shrink else c
+    want = orc.spatial_level_rec(cs, filt, 1)
+    L = len(filt[0][0])
+    t = _taps3(wname, 1, L)
+    src = to_kernel_order(c).astype(np.float32)
+    n2, n1 = src.shape[1:]
+    out = np.full((n2, n1), np.nan, dtype=np.float32)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    sh = shrink or (0.0, 0, 0)
+    assert emu.ndwt_emu2_inv2p_f32(L, depth, p(src), p(out), n1, n2, ychunk, p(t["syn_lo"]), p(t["syn_hi"]), ctypes.c_double(sh[0]), sh[1], sh[2]) == 0
+    got = np.transpose(out)
+    assert np.isfinite(got).all()
+    bad = np.abs(got - want) > 4e-6 * max(np.abs(want).max(), 1.0)
+    assert bad.mean() <= (2e-3 if shrink and shrink[2] else 0.0), float(np.abs(got - want).max())

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B of the row-chunk size of the fused 2-D kernels on cfg2 (4096x4096 fp32 db4 L3).
-python tools/ab_2d.py ychunk[,ychunk...]   (0 = the library's choice)"""
+python tools/ab_2d.py ychunk[,ychunk...] [n]   (0 = the library's choice; NDWT_VARIANT_INV: 1 Inv2S, 0 / 4 Inv2P depth 2 / 4,
+6 / 8 the same on half as many waves)"""
 import importlib
 import sys
 
@@ -9,7 +10,7 @@ import torch
 sys.path.insert(0, ".")
 api = importlib.import_module("non-decimated_wavelets_amd.api")
 ycs = [int(v) for v in sys.argv[1].split(",")]
-n1 = n2 = 4096
+n1 = n2 = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 level = 3
 plan = api.Plan([n1, n2], ["db4", "db4"], torch.float32, False, True, "reference", max_level=3).set_variant_from_env()
 x = torch.randn(n2, n1, device="cuda")
