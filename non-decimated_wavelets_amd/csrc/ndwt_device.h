@@ -589,10 +589,22 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
                 }
                 continue;
             }
-            T* b00 = a.out[2 * q] + off;
-            T* b10 = a.out[2 * q + 1] + off;
-            T* b01 = a.out[2 * q + 4] + off;
-            T* b11 = a.out[2 * q + 5] + off;
+            // Indexing the kernel-argument array with the per-lane q makes hipcc FETCH the four pointers with vector loads in every plane
+            // and wait vmcnt(0) for them -- i.e. also for the next plane's prefetch -- before the stores.  Selects avoid that: double
+            // -5 % (512^3) .. -10 % (256^3) per launch.  Float runs 1.7 % SLOWER without that wait (interleaved A/B, 512^3: 0.902 vs
+            // 0.917 ms; the wait keeps the waves of a workgroup in step, as DESIGN_HISTORY.md notes for the synthesis kernel) and keeps it.
+            T *b00, *b10, *b01, *b11;
+            if constexpr (sizeof(T) == 8) {
+                b00 = (q ? a.out[2] : a.out[0]) + off;
+                b10 = (q ? a.out[3] : a.out[1]) + off;
+                b01 = (q ? a.out[6] : a.out[4]) + off;
+                b11 = (q ? a.out[7] : a.out[5]) + off;
+            } else {
+                b00 = a.out[2 * q] + off;
+                b10 = a.out[2 * q + 1] + off;
+                b01 = a.out[2 * q + 4] + off;
+                b11 = a.out[2 * q + 5] + off;
+            }
             if constexpr (VEC4) {
                 stream_store(reinterpret_cast<v4*>(b00), o00, a.nt);
                 stream_store(reinterpret_cast<v4*>(b10), o10, a.nt);
