@@ -459,6 +459,16 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
         (long long)((a.n1 + 63) / 64) * ((a.n2 + 31) / 32) * a.nbatch >= 32)
         variant = 2;
     if (ttaps) variant = 6;                               // the folded t axis runs on the tall tile with y items of 2 rows
+    // float real analysis with 10 / 12 / 14 taps: the tall-tile kernel with its taps pinned in SGPRs and the high-pass ones derived from
+    // the low-pass ones (Fwd3 PIN: no scalar loads in the plane loop; 512^3 db5 0.945 -> 0.889, db6 1.027 -> 0.967, db7 1.118 -> 1.103 ms
+    // per launch, bit-identical).  Needs vec4 data and an even zero padding of every axis' taps; NDWT_VARIANT_FWD=8 keeps the plain
+    // form (A/B).  (6 / 8 taps: +1 %, not used; 16 taps spill in this form.)
+    bool pin_fwd = false;
+    if (!inverse && sizeof(T) == 4 && ew == 1 && !ttaps && (variant == 0 || variant == 8)) {
+        pin_fwd = variant == 0 && Lp >= 10 && Lp <= 14 && vec4;
+        for (int ax = 0; ax < 3; ++ax) pin_fwd = pin_fwd && (ax >= p->ndim || ((Lp - p->filt[ax].len) / 2) % 2 == 0);
+        if (variant == 8) variant = (Lp >= 6 && Lp <= 8 && (long long)((a.n1 + 63) / 64) * ((a.n2 + 31) / 32) * a.nbatch >= 32) ? 2 : 0;
+    }
     // double analysis, 6 and 8 taps: 64x16 tile with 512 threads, one column per thread (384^3 db4: 1.29 -> 0.97 ms per launch,
     // 320^3 -15 %, 512^3 -2 %, 256^3 +2 %); NDWT_VARIANT_FWD=3 keeps the 64x8 tile with 256 threads
     if (!inverse && sizeof(T) == 8 && ew == 1 && variant == 0 && Lp >= 6 && Lp <= 8) variant = 1;
@@ -510,6 +520,7 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
                 return fail(NDWT_ERR_UNSUPPORTED, "internal: no folded-t analysis kernel for tap length %d / this alignment", Lp);
             }
         }
+        if (rc == -1 && pin_fwd) rc = launch_fwd3_pin_f32(a, Lp, td, s);
         if (rc == -1 && Lp > 12 && ew == 1) rc = launch_long3_f32(inverse, a, t, vec4, variant, td, s);
     }
     if (rc == -1) rc = launch3<T>(inverse, a, t, vec4, ew != 1 ? (cplx_tall ? 2 : 0) : variant, ew, td, s);

@@ -353,6 +353,57 @@ template <int RSB> struct RowPair {
     static constexpr int slots(int nrows) { return ((nrows + 2 * M - 1) / (2 * M)) * (2 * M); }
 };
 
+// ---- packed FMAs with explicit operand selection (v_pk_fma_f32 op_sel / neg modifiers), float only ----
+// Why by hand: (1) hipcc keeps a scalar multiplier of a packed FMA as a DUPLICATED SGPR pair (t, t), which for the taps of three
+// axes overflows the SGPR file, so the compiler re-loads them from constant memory (s_load + lgkmcnt(0), which also drains the LDS
+// queue) inside the plane loop; (2) the high-pass taps are the low-pass taps mirrored with alternating signs, which the hardware
+// applies for free through op_sel (swap the halves of a tap pair) and neg_lo / neg_hi.  Tap pairs pinned in SGPRs ("+s" through an
+// empty asm) stay there across the plane loop.  The statements are not volatile: the compiler still schedules them.
+struct PkF32 {
+    typedef VecT<float>::v2 v2;
+    static NDWT_DEV v2 pinned(v2 t) {
+#ifndef NDWT_HOST_EMU
+        asm volatile("" : "+s"(t));
+#endif
+        return t;
+    }
+    // acc += (a[SELA], a[SELA]) * (t0, t1) with (t0, t1) = tp, or (tp[1], tp[0]) if SWAP; NEGLO / NEGHI negate t0 / t1.
+    template <int SELA, bool SWAP, bool NEGLO, bool NEGHI> static NDWT_DEV void fma_bt(v2& acc, const v2 a, const v2 tp) {
+#ifndef NDWT_HOST_EMU
+#define NDWT_PKF(A, S, NS, NL, NH)                                                                                                  \
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[" #A "," #S ",0] op_sel_hi:[" #A "," #NS ",1] neg_lo:[0," #NL ",0] neg_hi:[0," #NH ",0]" \
+            : "+v"(acc) : "v"(a), "s"(tp))
+        if constexpr (SELA == 0 && !SWAP) NDWT_PKF(0, 0, 1, 0, 0);
+        else if constexpr (SELA == 1 && !SWAP) NDWT_PKF(1, 0, 1, 0, 0);
+        else if constexpr (SELA == 0 && NEGLO) NDWT_PKF(0, 1, 0, 1, 0);
+        else if constexpr (SELA == 1 && NEGLO) NDWT_PKF(1, 1, 0, 1, 0);
+        else if constexpr (SELA == 0) NDWT_PKF(0, 1, 0, 0, 1);
+        else NDWT_PKF(1, 1, 0, 0, 1);
+#undef NDWT_PKF
+        static_assert(SWAP ? (NEGLO != NEGHI) : (!NEGLO && !NEGHI), "forms used by the x stages");
+#else
+        acc.x += a[SELA] * (NEGLO ? -tp[SWAP ? 1 : 0] : tp[SWAP ? 1 : 0]);
+        acc.y += a[SELA] * (NEGHI ? -tp[SWAP ? 0 : 1] : tp[SWAP ? 0 : 1]);
+#endif
+    }
+    // acc += x * (t, t), t = tp[HI], negated if NEG
+    template <int HI, bool NEG> static NDWT_DEV void fma_s(v2& acc, const v2 x, const v2 tp) {
+#ifndef NDWT_HOST_EMU
+        if constexpr (HI == 0 && !NEG) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(x), "s"(tp));
+        else if constexpr (HI == 1 && !NEG) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "s"(tp));
+        else if constexpr (HI == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "+v"(acc) : "v"(x), "s"(tp));
+        else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "+v"(acc) : "v"(x), "s"(tp));
+#else
+        acc += x * (NEG ? -tp[HI] : tp[HI]);
+#endif
+    }
+    // acc += x * ANALYSIS low-pass tap J (HIGH = false) or high-pass tap J = (-1)^J low-pass tap L-1-J, from the pairs lo[m] = (t[2m], t[2m+1])
+    template <int L, int J, bool HIGH> static NDWT_DEV void tap_ana(v2& acc, const v2 x, const v2 (&lo)[L / 2]) {
+        constexpr int jj = HIGH ? L - 1 - J : J;
+        fma_s<jj & 1, HIGH && (J % 2 == 1)>(acc, x, lo[jj / 2]);
+    }
+};
+
 // ---------------------------------------------------------------------------------- analysis ----
 // EW = scalars per element along x: 1 real, 2 interleaved complex (n1 then counts scalars and the x taps step over
 // (re, im) pairs; the y and z stages are component-wise and do not change)
@@ -361,9 +412,14 @@ template <int RSB> struct RowPair {
 // TPRE_: the t axis of a 4-D level folded in (Fused3Args::tt): the raw plane of frame t is the t-filtered combination of L frames,
 // so a 4-D level needs no pass of its own over the data for the t axis (17 volume transfers instead of 21: the t pass wrote two
 // volumes and the fused launches read them back)
-template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, int WPE_ = 2, int EW_ = 1, bool LOWONLY_ = false, bool TPRE_ = false> struct Fwd3 {
+// PIN_ (float): the taps as pairs pinned in SGPRs for the whole plane loop, the high-pass ones derived from the low-pass ones by the operand
+// modifiers of the packed FMA (PkF32) -- 4 L SGPRs instead of 12 L, so nothing is re-loaded from constant memory inside the loop (the
+// plain form issues 27 scalar loads per plane with 8 taps, 40 with 12).  Needs even zero padding of every axis' taps (the host checks).
+template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, int WPE_ = 2, int EW_ = 1, bool LOWONLY_ = false, bool TPRE_ = false,
+          bool PIN_ = false> struct Fwd3 {
     static constexpr int L = L_, TX = TX_, TY = TY_, NT = NT_, RY = RY_, EW = EW_;
-    static constexpr bool LOWONLY = LOWONLY_, TPRE = TPRE_;
+    static constexpr bool LOWONLY = LOWONLY_, TPRE = TPRE_, PIN = PIN_;
+    static_assert(!PIN_ || sizeof(T) == 4, "pinned / derived taps: float only (v_pk_fma_f32)");
     static_assert(!TPRE_ || VEC4_, "the folded t axis exists for rows of whole groups of 4 scalars");
     static constexpr bool VEC4 = VEC4_;
     static constexpr int NE = VEC4 ? 1 : 4;              // offsets kept per column
@@ -402,6 +458,21 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
         int off[NCOL][NE];
     };
     struct TFrames { long long off[L]; };                // TPRE: element offsets of the L frames under the t filter of this workgroup's frame
+    struct RegT {                                        // PIN: tap pairs in SGPRs
+        v2 ax[PIN ? L / 2 : 1], ay[PIN ? L / 2 : 1];     // (lo[2m], lo[2m+1]) of the x and y axes
+        v2 az[PIN ? L : 1];                              // (lo_z[j], hi_z[j])
+    };
+    static NDWT_DEV void load_regt(RegT& rt, const Taps& tp) {
+        if constexpr (PIN) {
+            NDWT_SFOR(m, L / 2)
+                rt.ax[m] = PkF32::pinned(v2{tp.lo[0][2 * m], tp.lo[0][2 * m + 1]});
+                rt.ay[m] = PkF32::pinned(v2{tp.lo[1][2 * m], tp.lo[1][2 * m + 1]});
+            NDWT_SEND
+            NDWT_SFOR(j, L)
+                rt.az[j] = PkF32::pinned(v2{tp.lo[2][j], tp.hi[2][j]});
+            NDWT_SEND
+        }
+    }
 
     static NDWT_DEV void setup(State& st, const Args& a, const TileCoord& tc, int tid) {
         NDWT_SFOR(k, NCOL)
@@ -462,7 +533,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
     }
 
     // rotation R: the newest plane lands in slot (R+L-1)%L; tap j reads slot (R+j)%L
-    template <int R> static NDWT_DEV void zstage(State& st, Shared& sh, const Taps& tp, int tid) {
+    template <int R> static NDWT_DEV void zstage(State& st, Shared& sh, const Taps& tp, const RegT& rt, int tid) {
         NDWT_SFOR(k, NCOL)
             st.win[k][(R + L - 1) % L] = st.nxt[k];
             int c = tid + k * NT;
@@ -471,18 +542,26 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
                 acc[0] = acc[1] = acc[2] = acc[3] = (v2)(T(0));
                 NDWT_SFOR(j, L)
                     v4 w = st.win[k][(R + j) % L];
-                    v2 t = {tp.lo[2][j], tp.hi[2][j]};
-                    acc[0] += t * w[0]; acc[1] += t * w[1]; acc[2] += t * w[2]; acc[3] += t * w[3];
+                    if constexpr (PIN) {                  // (lo, hi) += w[e] * (lo_z[j], hi_z[j]): the sample broadcast from a half of its register pair
+                        const v2 w01 = {w[0], w[1]}, w23 = {w[2], w[3]};
+                        PkF32::fma_bt<0, false, false, false>(acc[0], w01, rt.az[j]);
+                        PkF32::fma_bt<1, false, false, false>(acc[1], w01, rt.az[j]);
+                        PkF32::fma_bt<0, false, false, false>(acc[2], w23, rt.az[j]);
+                        PkF32::fma_bt<1, false, false, false>(acc[3], w23, rt.az[j]);
+                    } else {
+                        v2 t = {tp.lo[2][j], tp.hi[2][j]};
+                        acc[0] += t * w[0]; acc[1] += t * w[1]; acc[2] += t * w[2]; acc[3] += t * w[3];
+                    }
                 NDWT_SEND
                 int ug = c % NG, r = c / NG;
                 lds_store_run<T, 4>(sh.zs[r], 4 * ug, acc);
             }
         NDWT_SEND
     }
-    template <int R> static NDWT_DEV void zdispatch(int r, State& st, Shared& sh, const Taps& tp, int tid) {
+    template <int R> static NDWT_DEV void zdispatch(int r, State& st, Shared& sh, const Taps& tp, const RegT& rt, int tid) {
         if constexpr (R < L) {
-            if (r == R) zstage<R>(st, sh, tp, tid);
-            else zdispatch<R + 1>(r, st, sh, tp, tid);
+            if (r == R) zstage<R>(st, sh, tp, rt, tid);
+            else zdispatch<R + 1>(r, st, sh, tp, rt, tid);
         }
     }
     static NDWT_DEV void prologue(State& st, const Args& a, const T* inb, int zbeg) {
@@ -498,7 +577,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
     // time and scattered into the RY outputs they feed (the register footprint no longer grows with the tap length: what kept
     // tap lengths above 12 off the fused kernels)
     static constexpr int YGRP = 4;
-    static NDWT_DEV void ystage(Shared& sh, const Taps& tp, int tid) {
+    static NDWT_DEV void ystage(Shared& sh, const Taps& tp, const RegT& rt, int tid) {
         NDWT_UNROLL
         for (int k = 0; k < NYI; ++k) {
             int it = tid + k * NT;
@@ -525,8 +604,13 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
                             if constexpr (j >= 0 && j < L) {
                                 NDWT_SFOR(sub, CH)
                                     const v2 z = LD::get(zin[t], sub);
-                                    l[i][sub] += tp.lo[1][j] * z;
-                                    if constexpr (!LOWONLY) h[i][sub] += tp.hi[1][j] * z;
+                                    if constexpr (PIN) {
+                                        PkF32::tap_ana<L, j, false>(l[i][sub], z, rt.ay);
+                                        if constexpr (!LOWONLY) PkF32::tap_ana<L, j, true>(h[i][sub], z, rt.ay);
+                                    } else {
+                                        l[i][sub] += tp.lo[1][j] * z;
+                                        if constexpr (!LOWONLY) h[i][sub] += tp.hi[1][j] * z;
+                                    }
                                 NDWT_SEND
                             }
                         NDWT_SEND
@@ -548,7 +632,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
 
     // x filter + stores: item order (4-x group fastest, then y-bit, then row): the two 16-lane halves of a
     // 32-lane group read the two y-bit planes of one row
-    static NDWT_DEV void xstage(Shared& sh, const Taps& tp, const Args& a, const TileCoord& tc, long long obase, int z,
+    static NDWT_DEV void xstage(Shared& sh, const Taps& tp, const RegT& rt, const Args& a, const TileCoord& tc, long long obase, int z,
                                 int tid) {
         NDWT_UNROLL
         for (int k = 0; k < NXI; ++k) {
@@ -568,10 +652,17 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
             NDWT_UNROLL
             for (int e = 0; e < 4; ++e) {
                 v2 lo = (v2)(T(0)), hi = (v2)(T(0));
-                NDWT_UNROLL
-                for (int j = 0; j < L; ++j) {
-                    lo += tp.lo[0][j] * v[4 * GL + e + (j - LH) * EW];
-                    if constexpr (!LOWONLY) hi += tp.hi[0][j] * v[4 * GL + e + (j - LH) * EW];
+                if constexpr (PIN) {
+                    NDWT_SFOR(j, L)
+                        PkF32::tap_ana<L, j, false>(lo, v[4 * GL + e + (j - LH) * EW], rt.ax);
+                        if constexpr (!LOWONLY) PkF32::tap_ana<L, j, true>(hi, v[4 * GL + e + (j - LH) * EW], rt.ax);
+                    NDWT_SEND
+                } else {
+                    NDWT_UNROLL
+                    for (int j = 0; j < L; ++j) {
+                        lo += tp.lo[0][j] * v[4 * GL + e + (j - LH) * EW];
+                        if constexpr (!LOWONLY) hi += tp.hi[0][j] * v[4 * GL + e + (j - LH) * EW];
+                    }
                 }
                 o00[e] = lo.x; o01[e] = lo.y; o10[e] = hi.x; o11[e] = hi.y;
             }
@@ -629,6 +720,8 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
         const TileCoord tc = decode_tile<T, TPRE>(a, bid, TX, TY, VEC4 ? -1 : 4 * GL, 4 * GR);
         const T* inb = a.in[0] + batch_base(tc.batch, a.bsplit, a.in_bstride, a.in_bstride2);
         const long long obase = batch_base(tc.batch, a.bsplit, a.out_bstride, a.out_bstride2);
+        RegT rt;
+        load_regt(rt, tp);
         TFrames tf;
         if constexpr (TPRE) {                             // frames t - LH .. t + RH of the periodic t axis (the batch index)
             NDWT_SFOR(j, L)
@@ -660,14 +753,14 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
             const int z = tc.zbeg + s;
             ex.each([&](int tid, State& st) __attribute__((always_inline)) {
                 if constexpr (TPRE) tcombine(st, a);                      // the prefetched frames -> the t-filtered raw plane
-                zdispatch<0>(s % L, st, sh, tp, tid);                     // consumes st.nxt
+                zdispatch<0>(s % L, st, sh, tp, rt, tid);                 // consumes st.nxt
                 if (s + 1 < nsteps) fetch(st, z + 1 + RH);                // prefetch for the next step
             });
             ex.barrier();
             NDWT_SETPRIO(1);                              // the stages that end in this plane's stores go ahead of the other
-            ex.each([&](int tid, State&) __attribute__((always_inline)) { ystage(sh, tp, tid); });   // waves' loads (-2 %)
+            ex.each([&](int tid, State&) __attribute__((always_inline)) { ystage(sh, tp, rt, tid); });   // waves' loads (-2 %)
             ex.barrier();
-            ex.each([&](int tid, State&) __attribute__((always_inline)) { xstage(sh, tp, a, tc, obase, z, tid); });
+            ex.each([&](int tid, State&) __attribute__((always_inline)) { xstage(sh, tp, rt, a, tc, obase, z, tid); });
             NDWT_SETPRIO(0);
         }
     }
@@ -1368,34 +1461,10 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
     // lanes (v_readlane) inside it.  The statements are not volatile: the compiler still schedules them.
     // acc += (a[SELA], a[SELA]) * (t0, t1) with (t0, t1) = tp, or (tp[1], tp[0]) if SWAP; NEGLO / NEGHI negate t0 / t1.
     template <int SELA, bool SWAP, bool NEGLO, bool NEGHI> static NDWT_DEV void pk_fma_bt(v2& acc, const v2 a, const v2 tp) {
-#ifndef NDWT_HOST_EMU
-#define NDWT_PKF(A, S, NS, NL, NH)                                                                                                  \
-        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[" #A "," #S ",0] op_sel_hi:[" #A "," #NS ",1] neg_lo:[0," #NL ",0] neg_hi:[0," #NH ",0]" \
-            : "+v"(acc) : "v"(a), "s"(tp))
-        if constexpr (SELA == 0 && !SWAP) NDWT_PKF(0, 0, 1, 0, 0);
-        else if constexpr (SELA == 1 && !SWAP) NDWT_PKF(1, 0, 1, 0, 0);
-        else if constexpr (SELA == 0 && NEGLO) NDWT_PKF(0, 1, 0, 1, 0);
-        else if constexpr (SELA == 1 && NEGLO) NDWT_PKF(1, 1, 0, 1, 0);
-        else if constexpr (SELA == 0) NDWT_PKF(0, 1, 0, 0, 1);
-        else NDWT_PKF(1, 1, 0, 0, 1);
-#undef NDWT_PKF
-        static_assert(SWAP ? (NEGLO != NEGHI) : (!NEGLO && !NEGHI), "forms used by the x stage");
-#else
-        acc.x += a[SELA] * (NEGLO ? -tp[SWAP ? 1 : 0] : tp[SWAP ? 1 : 0]);
-        acc.y += a[SELA] * (NEGHI ? -tp[SWAP ? 0 : 1] : tp[SWAP ? 0 : 1]);
-#endif
+        PkF32::fma_bt<SELA, SWAP, NEGLO, NEGHI>(acc, a, tp);
     }
     // acc += x * (t, t), t = tp[HI], negated if NEG
-    template <int HI, bool NEG> static NDWT_DEV void pk_fma_s(v2& acc, const v2 x, const v2 tp) {
-#ifndef NDWT_HOST_EMU
-        if constexpr (HI == 0 && !NEG) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(x), "s"(tp));
-        else if constexpr (HI == 1 && !NEG) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "s"(tp));
-        else if constexpr (HI == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "+v"(acc) : "v"(x), "s"(tp));
-        else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "+v"(acc) : "v"(x), "s"(tp));
-#else
-        acc += x * (NEG ? -tp[HI] : tp[HI]);
-#endif
-    }
+    template <int HI, bool NEG> static NDWT_DEV void pk_fma_s(v2& acc, const v2 x, const v2 tp) { PkF32::fma_s<HI, NEG>(acc, x, tp); }
     // acc += x * low-pass tap J (HIGH = false) or high-pass tap J = (-1)^(J+1) low-pass tap L-1-J, from the low-pass tap pairs `lo`
     template <int J, bool HIGH> static NDWT_DEV void tap_fma(v2& acc, const v2 x, const v2 (&lo)[L / 2]) {
         constexpr int jj = HIGH ? L - 1 - J : J;

@@ -20,6 +20,7 @@ void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int
 
 int launch_fwd3_f32(const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, int variant, int ew, const void* taps_dev, hipStream_t s);
 int launch_inv3_f32(const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, int variant, int ew, const void* taps_dev, hipStream_t s);
+int launch_fwd3_pin_f32(const Fused3Args<float>& a, int Lp, const void* taps_dev, hipStream_t s);   // 10 / 12 / 14 taps, tall tile, taps pinned in SGPRs (vec4 data)
 int launch_fwd3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4, int variant, int ew, const void* taps_dev, hipStream_t s);
 int launch_inv3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4, int variant, int ew, const void* taps_dev, hipStream_t s);
 

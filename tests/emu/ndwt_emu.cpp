@@ -546,6 +546,28 @@ extern "C" int ndwt_emu_low3_f32(int Lp, int vec4, const float* x, float* out, i
 }
 #endif
 
+#if EMU_IN(14)
+// the analysis kernel with its taps pinned in SGPRs and the high-pass taps derived from the low-pass ones (Fwd3<.., PIN>), production tile
+template <int LL> static int run_pin3(ndwt::Fused3Args<float>& a, const double* lo, const double* hi) {
+    typedef ndwt::Fused3Tile<float, false, 6> TL;
+    return run<ndwt::Fwd3<float, LL, TL::TX, TL::TY, TL::NT, TL::RY, true, 2, 1, false, false, true>, float>(a, lo, hi);
+}
+extern "C" int ndwt_emu_pin3_f32(int Lp, const float* x, float* out, int n1, int n2, int n3, int zchunk, const double* alo, const double* ahi) {
+    ndwt::Fused3Args<float> a;
+    std::memset(&a, 0, sizeof(a));
+    a.n1 = n1; a.n2 = n2; a.n3 = n3; a.nbatch = 1; a.z_wrap = 1;
+    a.in[0] = x;
+    for (int b = 0; b < 8; ++b) a.out[b] = out + (long long)b * n1 * n2 * n3;
+    ndwt::fused3_geometry(a, 64, 32, Lp, 4, zchunk);
+    switch (Lp) {
+        case 10: return run_pin3<10>(a, alo, ahi);
+        case 12: return run_pin3<12>(a, alo, ahi);
+        case 14: return run_pin3<14>(a, alo, ahi);
+        default: return -1;
+    }
+}
+#endif
+
 extern "C" {
 #if EMU_IN(1)
 int ndwt_emu_axisx_f32(int syn, int L, int ew, int vec4, const float* in0, const float* in1, float* out0, float* out1, long long row,

@@ -153,7 +153,8 @@ def test_headline_kernels_do_not_spill():
         "Inv3YIfLi8ELi64ELi32ELi1024ELb0ELi4ELi2",      # the same on rows that are not whole groups of 4 scalars
         "Inv3YIfLi12ELi64ELi32ELi1024ELb1ELi4ELi2",     # cfg4 (db6) synthesis: two register sets, 6 z sums in LDS
         "Fwd3IfLi8ELi64ELi32ELi1024ELi4ELb1",           # cfg3 / cfg5 analysis, tall tile
-        "Fwd3IfLi12ELi64ELi32ELi1024ELi2ELb1",          # cfg4 analysis
+        "Fwd3IfLi12ELi64ELi32ELi1024ELi2ELb1",          # cfg4 analysis (plain form and the pinned-tap form, ..ELb0ELb0ELb1)
+        "Fwd3IfLi10ELi64ELi32ELi1024ELi2ELb1", "Fwd3IfLi14ELi64ELi32ELi1024ELi2ELb1",
         "Fwd2SIfLi8ELb1", "Inv2SIfLi8ELb1", "Inv2PIfLi8ELi4E",   # cfg2 (synthesis: Inv2P, 4 rows in flight)
         "Den3IfLi2E", "Den3IfLi4E", "Den3IfLi6E", "Den3IfLi8E",
         "Inv3YIfLi18E", "Inv3YIfLi20E",

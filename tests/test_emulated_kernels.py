@@ -490,6 +490,34 @@ def test_emulated_approximation_only_analysis(emu, sizes, wname, vec4, zchunk):
 
 
 @pytest.mark.slow
+@pytest.mark.parametrize("sizes,wnames,zchunk", [((68, 36, 9), ("db6",) * 3, 0), ((72, 40, 16), ("db5",) * 3, 6), ((64, 32, 5), ("db7",) * 3, 0),
+                                                 ((128, 33, 7), ("db6", "db2", "db4"), 3), ((16, 12, 14), ("db6",) * 3, 0)])
+def test_emulated_analysis_with_pinned_taps(emu, sizes, wnames, zchunk):
+    """Fwd3<.., PIN> (float real, 10 / 12 / 14 taps on vec4 data): tap pairs pinned in scalar registers, the high-pass taps taken from
+    the low-pass pairs through the operand modifiers of the packed FMA (mirror + alternating signs, which survives an EVEN zero padding
+    of a shorter axis' taps) -- all 8 bands against the oracle"""
+    rng = np.random.default_rng(34)
+    x = rng.standard_normal(sizes)
+    filt = [orc.wave_filters(w) for w in wnames]
+    want = orc.spatial_level_dec(x, filt, 1)
+    L = max(len(f[0]) for f in filt)
+    t = {k: np.zeros((3, 20)) for k in ("ana_lo", "ana_hi")}
+    for ax, w in enumerate(wnames):
+        assert ((L - len(filt[ax][0])) // 2) % 2 == 0
+        ka = kernel_taps(w, 1, L)
+        for k in t:
+            t[k][ax, :L] = ka[k]
+    xs = to_kernel_order(x).astype(np.float32)
+    n3, n2, n1 = xs.shape
+    out = np.full((8, n3, n2, n1), np.nan, dtype=np.float32)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    assert emu.ndwt_emu_pin3_f32(L, p(xs), p(out), n1, n2, n3, zchunk, p(t["ana_lo"]), p(t["ana_hi"])) == 0
+    got = np.transpose(out)
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+
+
+@pytest.mark.slow
 @pytest.mark.parametrize("sizes,wname,zchunk", [((68, 36, 6, 5), "db4", 0), ((64, 32, 9, 3), "db2", 4), ((72, 33, 5, 9), "db1", 0)])
 def test_emulated_4d_analysis_with_folded_t_axis(emu, sizes, wname, zchunk):
     """Fwd3<.., TPRE>: a 4-D analysis level in two launches (one per t-band) whose raw planes are the t-filtered combination of L
