@@ -287,17 +287,17 @@ template <typename T> static int generic_synthesis(GenericCtx<T>& c, int axis, i
 
 // ------------------------------------------------------------------------------------ fused levels
 // dir: 0 analysis, 1 synthesis, -1 both.  Instantiated tap lengths: 2..12 (db1..db6) for every data kind the checks below let
-// through; float real data also 14 .. 20 (db7 .. db10; 18- and 20-tap synthesis with the pair-packed kernel only).
+// through; float real data also 14 .. 20 (db7 .. db10; 18- and 20-tap synthesis with the pair-packed kernel only), double real data 14 and 16.
 static bool inv3y_plan_ok(const ndwt_plan* p, int Lp);
 static bool fused3_eligible(const ndwt_plan* p, long long stride, int* Lp_out, int dir = -1) {
     if (p->path != NDWT_PATH_AUTO || stride != 1 || p->ndim < 3) return false;
     if (p->dtype == NDWT_F64 && !p->fp64_fused) return false;
     int Lp = 2;
     for (int a = 0; a < 3; ++a) Lp = p->filt[a].len > Lp ? p->filt[a].len : Lp;
-    const int lmax = (p->dtype == NDWT_F32 && p->complexity == NDWT_REAL) ? (dir == 0 ? 20 : 16) : 12;
+    const int lmax = p->complexity != NDWT_REAL ? 12 : (p->dtype == NDWT_F32 ? (dir == 0 ? 20 : 16) : 16);
     // 18- and 20-tap synthesis exist as the pair-packed kernel only (uniform wavelets, or mixed ones with even padding on every axis)
     if (Lp > lmax && !(dir == 1 && Lp <= 20 && inv3y_plan_ok(p, Lp))) return false;
-    if (p->dtype == NDWT_F64 && Lp > 12) return false;   // double: up to db6 (64x8 tiles with 512 threads keep 10 / 12 taps free of spills)
+    if (p->dtype == NDWT_F64 && Lp > 16) return false;   // double: up to db8 (64x8 tiles with 512 threads keep 10 .. 16 taps in 256 registers)
     // interleaved complex: the fused kernels with the x taps stepping over (re, im) pairs, tap lengths <= 8 (float: <= 12); rows of an
     // odd number of elements run the VEC4 = false instances (one access per lane wherever its 4 scalars are contiguous)
     if (p->complexity != NDWT_REAL && Lp > (p->dtype == NDWT_F32 ? 12 : 8)) return false;
@@ -522,6 +522,9 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
         }
         if (rc == -1 && pin_fwd) rc = launch_fwd3_pin_f32(a, Lp, td, s);
         if (rc == -1 && Lp > 12 && ew == 1) rc = launch_long3_f32(inverse, a, t, vec4, variant, td, s);
+    }
+    if constexpr (sizeof(T) == 8) {
+        if (Lp > 12 && ew == 1) rc = launch_long3_f64(inverse, a, t, vec4, td, s);
     }
     if (rc == -1) rc = launch3<T>(inverse, a, t, vec4, ew != 1 ? (cplx_tall ? 2 : 0) : variant, ew, td, s);
     prof_end(p, s, rc);

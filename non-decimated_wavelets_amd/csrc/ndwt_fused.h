@@ -38,6 +38,7 @@ int launch_fwd3_tpre_f32(const Fused3Args<float>& a, int Lp, const void* taps_de
 
 // float, tap lengths 14..18 (analysis) / 14..16 (synthesis): ndwt_fused3_f32_long.hip
 int launch_long3_f32(bool inverse, const Fused3Args<float>& a, const FusedTapsD& t, bool vec4, int variant, const void* taps_dev, hipStream_t s);
+int launch_long3_f64(bool inverse, const Fused3Args<double>& a, const FusedTapsD& t, bool vec4, const void* taps_dev, hipStream_t s);   // 14 / 16 taps
 
 // fused 2-D kernels (register-only, one wave per tile)
 int fused2_tile_width(bool inverse, int Lp, int ew);

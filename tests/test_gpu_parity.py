@@ -460,6 +460,30 @@ def test_long_filters_float(sizes, wn, path):
     assert _relerr(w.rec(y).cpu().numpy(), x) < 1e-5
 
 
+@pytest.mark.parametrize("sizes,wn,path", [
+    ([64, 40, 36], "db7", "fused3d"),                                  # 14 taps: 64 x 8 tiles, 512 threads
+    ([68, 41, 30], "db8", "fused3d"),                                  # 16 taps, ragged tiles
+    ([70, 37, 33], "db8", "fused3d"),                                  # ... rows that are not whole groups of 4 elements
+    ([64, 40, 36], ["db8", "db3", "db7"], "fused3d"),                  # mixed wavelets padded to 16 taps (odd and even padding)
+    ([64, 40, 36], "db9", "axis"),                                     # 18 / 20 taps: per-axis path (the fused form spills 400+ registers)
+])
+def test_long_filters_double(sizes, wn, path):
+    """db7 / db8 on real double data (the reference mex path's precision, Test/nddwt3D_test.m:11 wavelets): fused, parity with the oracle"""
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal(sizes)
+    w = ndwt.nd_dwt_3D(wn, sizes, "pres_l2_norm", 1, "precision", "double")
+    xg = _colmajor_gpu(x, "double")
+    y = w.dec(xg, 2)
+    assert list(w._plans.values())[0].describe() == path
+    wl = [wn] * 3 if isinstance(wn, str) else wn
+    assert _relerr(y.cpu().numpy(), orc.spatial_dec(x, wl, 2, 1)) <= TOL["double"]
+    c = rng.standard_normal(sizes + [15])
+    got = w.rec(_colmajor_gpu(c, "double")).cpu().numpy()
+    want = orc.spatial_rec(c, wl, 1)
+    assert np.abs(got - want).max() <= TOL["double"] * max(np.abs(want).max(), np.abs(c).max())
+    assert _relerr(w.rec(y).cpu().numpy(), x) < 1e-13
+
+
 @pytest.mark.parametrize("sizes,wn,precision,path", [
     ([32, 24, 20], "db5", "single", "fused3d"),
     ([34, 21, 19], "db6", "single", "fused3d"),
