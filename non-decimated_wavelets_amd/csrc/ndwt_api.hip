@@ -300,7 +300,8 @@ static bool fused3_eligible(const ndwt_plan* p, long long stride, int* Lp_out, i
     if (p->dtype == NDWT_F64 && Lp > 16) return false;   // double: up to db8 (64x8 tiles with 512 threads keep 10 .. 16 taps in 256 registers)
     // interleaved complex: the fused kernels with the x taps stepping over (re, im) pairs, tap lengths <= 8 (float: <= 12); rows of an
     // odd number of elements run the VEC4 = false instances (one access per lane wherever its 4 scalars are contiguous)
-    if (p->complexity != NDWT_REAL && Lp > (p->dtype == NDWT_F32 ? 12 : 8)) return false;
+    // (complex128: 10 taps both ways, 12 taps analysis only -- its synthesis spills 500+ registers on every tile)
+    if (p->complexity != NDWT_REAL && Lp > (p->dtype == NDWT_F32 ? 12 : (dir == 0 ? 12 : 10))) return false;
     long long nbatch = p->ndim == 4 ? p->dims[3] + 64 : 1;
     if (!fused3_fits(p->dims[0] * p->comp, p->dims[1], p->dims[2] + 64, nbatch)) return false;
     *Lp_out = Lp;
@@ -376,7 +377,7 @@ void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int
     if (ew != 1) variant = 0;
     *TX = 64;
     if (!inverse) {
-        *TY = f64 ? ((Lp == 10 || (variant == 1 && Lp >= 6 && Lp <= 8 && ew == 1) || (ew == 2 && Lp == 8)) ? 16 : 8) : 16;   // double: db5, complex db4 (db3/db4: variant 1) 64x16 with 512 threads; db6 64x8 with 512
+        *TY = f64 ? (((Lp == 10 && ew == 1) || (variant == 1 && Lp >= 6 && Lp <= 8 && ew == 1) || (ew == 2 && Lp == 8)) ? 16 : 8) : 16;   // double: db5, complex db4 (db3/db4: variant 1) 64x16 with 512 threads; db6 64x8 with 512
         if (!f64 && ew == 1 && (((variant == 2 || variant == 6) && Lp <= 8) || (variant != 1 && Lp >= 10 && Lp <= 16))) *TY = 32;   // float, tall tile: 10 .. 16 taps (<= 8: A/B)
     } else if (f64) {
         *TY = ((variant == 3 && Lp == 8) || Lp >= 10) ? 8 : 16;                   // lane-shift kernel 64x16 (10 / 12 taps: 64x8); variant 3 = LDS kernel

@@ -9,6 +9,8 @@ int launch_fwd3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4,
             NDWT_FUSED_CASE_C(Fwd3, false, double, 4, 0)
             NDWT_FUSED_CASE_C(Fwd3, false, double, 6, 0)
             NDWT_FUSED_CASE_C(Fwd3, false, double, 8, 1)   // 64x16 tile, 512 threads: the 256-thread tile spills 16 registers (256^3: 0.97 -> 0.58 ms per launch)
+            NDWT_FUSED_CASE_C(Fwd3, false, double, 10, 5)  // 64x8 tile, 512 threads
+            NDWT_FUSED_CASE_C(Fwd3, false, double, 12, 5)  // (16 spilled registers)
             default: return -1;
         }
     }

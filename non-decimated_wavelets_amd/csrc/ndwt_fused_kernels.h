@@ -137,6 +137,7 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
             NDWT_FUSED_CASE_C(Inv3S, true, T, 4, 1)                       \
             NDWT_FUSED_CASE_C(Inv3S, true, T, 6, 1)                       \
             NDWT_FUSED_CASE_C(Inv3S, true, T, 8, 1)                       \
+            NDWT_FUSED_CASE_C(Inv3S, true, T, 10, 5)   /* complex128 db5: 64x8 tile, 512 threads (6 spilled registers) */ \
             default: return -1;                                           \
         }                                                                 \
     }                                                                     \

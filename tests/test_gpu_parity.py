@@ -489,7 +489,10 @@ def test_long_filters_double(sizes, wn, path):
     ([34, 21, 19], "db6", "single", "fused3d"),
     ([32, 24, 20], ["db6", "db2", "db5"], "single", "fused3d"),
     ([32, 24, 20], "db7", "single", "axis"),
-    ([32, 24, 20], "db5", "double", "axis"),                           # complex128: fused up to 8 taps
+    ([32, 24, 20], "db5", "double", "fused3d"),                        # complex128: fused up to 10 taps,
+    ([34, 21, 19], "db5", "double", "fused3d"),
+    ([32, 24, 20], "db6", "double", "fused3d analysis, axis synthesis"),   # ... 12 taps in the analysis only
+    ([32, 24, 20], "db7", "double", "axis"),
 ])
 def test_long_filters_complex(sizes, wn, precision, path):
     """interleaved complex data with 10 / 12 taps: fused in single precision (x taps step over (re, im) pairs)"""
