@@ -477,7 +477,9 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     if (cplx_tall) TY = 32;
     bool use_y = false;                                   // float synthesis default: the pair-packed kernel and its tile
     if constexpr (sizeof(T) == 4) {
-        use_y = inverse && dil == 1 && inv3y_plan_ok(p, Lp);   // (plane offsets stay below 2^32 bytes: checked there)
+        // (plane offsets stay below 2^32 bytes: checked there).  A level dilated by 2 on real data is the interleaved-pair form of the
+        // kernel (the two x sub-lattices are its (re, im) halves): 512^3 db4 synthesis at tap stride 2 1.52 -> see DESIGN 4.6
+        use_y = inverse && (dil == 1 || (dil == 2 && p->comp == 1 && p->variant_inv != 2)) && inv3y_plan_ok(p, Lp);
         if (use_y) { TX = ndwt::inv3y_tx(Lp, ew); TY = ndwt::inv3y_ty(Lp, ew); }
     }
     const int zc_force = p->zchunk_dir[inverse ? 1 : 0] > 0 ? p->zchunk_dir[inverse ? 1 : 0] : p->force_zchunk;
