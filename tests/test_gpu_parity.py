@@ -1018,6 +1018,48 @@ def test_one_plan_serves_several_torch_streams():
         assert _relerr(r.cpu().numpy(), x) < 20 * TOL["single"]
 
 
+@pytest.mark.parametrize("d,sizes,wn,precision", [(3, [64, 40, 36], "db4", "single"), (2, [260, 64], "db3", "single"), (1, [4096], "db2", "double"),
+                                                  (3, [48, 40, 36], "db2", "double"), (4, [24, 20, 16, 12], "db2", "single")])
+def test_dec_rec_and_denoise_are_graph_capturable(d, sizes, wn, precision):
+    """a long-lived plan's dec / rec / denoise enqueue kernels and nothing else (no allocation, copy from the host or synchronisation once
+    the plan is warm), so a solver iteration can be captured into a HIP graph and replayed; the replay reproduces the eager results on
+    new input data"""
+    dt = torch.float32 if precision == "single" else torch.float64
+    plan = ndwt.Plan(sizes, [wn] * d, dt, False, True, "reference", max_level=2)
+    nb = ndwt.num_bands(d, 2)
+    shp = tuple(reversed(sizes))
+    x = torch.randn(*shp, device="cuda", dtype=dt)
+    y = torch.empty((nb,) + shp, device="cuda", dtype=dt)
+    r, den = torch.empty_like(x), torch.empty_like(x)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for _ in range(2):                                  # warm: scratch of the plan allocated outside the capture
+            plan.dec(x.data_ptr(), y.data_ptr(), 2, st.cuda_stream)
+            plan.rec(y.data_ptr(), r.data_ptr(), 2, st.cuda_stream)
+            plan.denoise(x.data_ptr(), den.data_ptr(), 2, 0.3, 0, st.cuda_stream)
+    st.synchronize()
+    y0, r0, d0 = y.clone(), r.clone(), den.clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=st):
+        plan.dec(x.data_ptr(), y.data_ptr(), 2, st.cuda_stream)
+        plan.rec(y.data_ptr(), r.data_ptr(), 2, st.cuda_stream)
+        plan.denoise(x.data_ptr(), den.data_ptr(), 2, 0.3, 0, st.cuda_stream)
+    y.zero_(); r.zero_(); den.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, y0) and torch.equal(r, r0) and torch.equal(den, d0)
+    x2 = torch.randn_like(x)
+    x.copy_(x2)
+    g.replay()
+    torch.cuda.synchronize()
+    yg, rg, dg = y.clone(), r.clone(), den.clone()
+    plan.dec(x.data_ptr(), y.data_ptr(), 2, 0)
+    plan.rec(y.data_ptr(), r.data_ptr(), 2, 0)
+    plan.denoise(x.data_ptr(), den.data_ptr(), 2, 0.3, 0, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(y, yg) and torch.equal(r, rg) and torch.equal(den, dg)
+
+
 def test_sharded_driver_band_pitch_option():
     """ShardedNdDwt(band_pitch='packed') returns a contiguous coefficient slab (for callers that pass it to collectives or take raw
     pointers); the default 'auto' returns the pitched view; the values are the same"""
