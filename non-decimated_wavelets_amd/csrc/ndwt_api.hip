@@ -579,6 +579,8 @@ static int fused2_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     // exactly the load a row needs, half as many waves on chunks twice as long (the L-1 prologue rows of a chunk are re-read).  Interleaved
     // A/B, 3 levels of rec: 1024^2 52 -> 43 us, 2048^2 81 -> 80, 4096^2 289 -> 265; 8192^2 927 -> 961 (not taken there: the run needs
     // more than one round of waves either way).  variant_inv: 1 keeps Inv2S, 2 / 4 = depth on Inv2S's geometry, 6 = depth 2 on 1024 waves.
+    // Depth 4 runs in the packed form (pairs of adjacent x outputs per v_pk_fma_f32, tap pairs pinned in SGPRs; variant_inv 7 = scalar FMAs):
+    // 4096^2 db4 74 us either way (the kernel sits on its memory floor), db6 116 -> 98 us, 2048^2 db4 27.1 -> 25.1 us per level.
     const int tiles2 = (a.n1 + fused2_tile_width(inverse, Lp, ew2) - 1) / fused2_tile_width(inverse, Lp, ew2);
     const bool deep = inverse && sizeof(T) == 4 && ew2 == 1 && dil == 1 && vec4 && p->variant_inv != 1 && n2 >= 64 &&
                       ((long long)tiles2 * ((n2 + 69) / 70) <= 1280 || p->variant_inv >= 2);
@@ -592,7 +594,7 @@ static int fused2_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     prof_begin(p, inverse ? NDWT_KERNEL_FUSED_SYNTHESIS : NDWT_KERNEL_FUSED_ANALYSIS, s);
     int rc = -1;
     if constexpr (sizeof(T) == 4) {
-        if (deep) rc = launch_inv2p_f32(a, Lp, pdepth, td, s);
+        if (deep) rc = launch_inv2p_f32(a, Lp, pdepth, td, s, p->variant_inv != 7);
     }
     if (rc == -1) rc = launch2<T>(inverse, a, Lp, vec4, ew2, td, s);
     prof_end(p, s, rc);

@@ -2350,15 +2350,21 @@ template <typename T, int L_, bool VEC4_, int WPE_ = 4, int EW_ = 1> struct Inv2
 // vmcnt(0) at the first use, so a wave exposes one full memory latency per row and the kernel needs 8 waves per CU on chunks so short that
 // the L-1 prologue rows re-read 20 % of every chunk (FETCH_SIZE 1.40x the bands at 4096^2).  Here the compiler sees which load feeds which
 // row and waits for exactly that one.  Float / double real data in rows of whole groups of 4 scalars; everything else keeps Inv2S.
-template <typename T, int L_, int PD_ = 2, int WPE_ = 2> struct Inv2P {
+// PK_ (float): the arithmetic as packed FMAs on pairs of adjacent x outputs -- x stage: (out[e], out[e+1]) += w * (t[k], t[k-1]) with the
+// neighbour's sample w broadcast from one half of its register pair and the tap pairs of Taps3Y pinned in SGPRs; y stage: a tap broadcast
+// from an SGPR pair.  104 packed FMAs per row and lane instead of 192 scalar ones (L = 8).
+template <typename T, int L_, int PD_ = 2, int WPE_ = 2, bool PK_ = false> struct Inv2P {
     static constexpr int L = L_, NT = 64, WPE = WPE_, PD = PD_;
+    static constexpr bool PK = PK_;
     static_assert(L % PD == 0, "the depth divides the tap length: a row's slot is p % PD with p = group base + k");
+    static_assert(!PK_ || sizeof(T) == 4, "packed form: float only (v_pk_fma_f32)");
     static constexpr int LH = L / 2, RH = L / 2 - 1;
     static constexpr int GL = (LH + 3) / 4, GR = (RH + 3) / 4;
     static constexpr int WX = 4 * (64 - GL - GR);
     static constexpr int XV = 4 * (1 + GL + GR);
     typedef typename VecT<T>::v4 v4;
-    typedef Taps3<T, L> Taps;
+    typedef typename VecT<T>::v2 v2;
+    typedef Taps3Y<T, L> Taps;      // (its first two members are Taps3<T, L>; the x tap pairs are read by the packed form only)
     typedef Fused2Args<T> Args;
     struct Shared { int unused; };
     struct State {
@@ -2366,6 +2372,22 @@ template <typename T, int L_, int PD_ = 2, int WPE_ = 2> struct Inv2P {
         v4 raw[PD][4];     // 4 x of every band of the rows in flight: row p in slot p % PD
         int off;
     };
+    struct RegT {          // PK: tap pairs pinned in SGPRs
+        v2 xl[PK ? L + 1 : 1], xh[PK ? L + 1 : 1];    // (t[k], t[k-1]) of the x low-pass / high-pass taps
+        v2 yl[PK ? L / 2 : 1], yh[PK ? L / 2 : 1];    // (t[2m], t[2m+1]) of the y taps
+    };
+    static NDWT_DEV void load_regt(RegT& rt, const Taps& tp) {
+        if constexpr (PK) {
+            NDWT_SFOR(k, L + 1)
+                rt.xl[k] = PkF32::pinned(v2{tp.xplo[k][0], tp.xplo[k][1]});
+                rt.xh[k] = PkF32::pinned(v2{tp.xphi[k][0], tp.xphi[k][1]});
+            NDWT_SEND
+            NDWT_SFOR(m, L / 2)
+                rt.yl[m] = PkF32::pinned(v2{tp.lo[1][2 * m], tp.lo[1][2 * m + 1]});
+                rt.yh[m] = PkF32::pinned(v2{tp.hi[1][2 * m], tp.hi[1][2 * m + 1]});
+            NDWT_SEND
+        }
+    }
     template <int S> static NDWT_DEV void load_row(State& st, const Args& a, long long ibase, int yraw) {
         const long long ym = a.y_wrap ? (long long)modn(yraw, a.n2) : (long long)(yraw + LH);
         NDWT_SFOR(b, 4)
@@ -2380,6 +2402,52 @@ template <typename T, int L_, int PD_ = 2, int WPE_ = 2> struct Inv2P {
         }
     }
     // row p = group base + K (rotation R = (K + 1) % L, slot K % PD): x-synthesis via lane shifts, y-synthesis in scatter form
+    // the packed form of step<K>
+    template <int K, class Exec>
+    static NDWT_DEV void step_pk(Exec& ex, State& st, const RegT& rt, const Args& a, const Tile2Coord& tc, long long obase, int y, bool emit, int tid) {
+        constexpr int R = (K + 1) % L, S = K % PD;
+        v2 P[2][2];                                       // [y band][x outputs (0, 1) / (2, 3)]
+        P[0][0] = P[0][1] = P[1][0] = P[1][1] = (v2)(T(0));
+        NDWT_SFOR(ii, XV / 2)
+            constexpr int i0 = 2 * ii;
+            constexpr int D = i0 / 4 - GL;
+            constexpr int c = i0 % 4;                     // 0 or 2: the register pair (c, c + 1) of the lane D away
+            v2 w[4];
+            NDWT_SFOR(b, 4)
+                w[b] = v2{NDWT_LANE_SHIFT(ex, tid, D, s.raw[S][b][c]), NDWT_LANE_SHIFT(ex, tid, D, s.raw[S][b][c + 1])};
+            NDWT_SEND
+            NDWT_SFOR(h, 2)
+                constexpr int k0 = i0 + h - 4 * GL + LH;  // tap pair of the outputs (0, 1); (2, 3): two taps earlier
+                NDWT_SFOR(q, 2)
+                    constexpr int k = k0 - 2 * q;
+                    if constexpr (k >= 0 && k <= L) {
+                        PkF32::fma_bt<h, false, false, false>(P[0][q], w[0], rt.xl[k]);
+                        PkF32::fma_bt<h, false, false, false>(P[0][q], w[1], rt.xh[k]);
+                        PkF32::fma_bt<h, false, false, false>(P[1][q], w[2], rt.xl[k]);
+                        PkF32::fma_bt<h, false, false, false>(P[1][q], w[3], rt.xh[k]);
+                    }
+                NDWT_SEND
+            NDWT_SEND
+        NDWT_SEND
+        NDWT_SFOR(j, L)
+            constexpr int slot = ((R - 1 - j) % L + L) % L;
+            NDWT_SFOR(q, 2)
+                v2 acc;
+                if constexpr (j == 0) acc = (v2)(T(0));
+                else acc = v2{st.yacc[slot][2 * q], st.yacc[slot][2 * q + 1]};
+                PkF32::fma_s<j % 2, false>(acc, P[0][q], rt.yl[j / 2]);
+                PkF32::fma_s<j % 2, false>(acc, P[1][q], rt.yh[j / 2]);
+                st.yacc[slot][2 * q] = acc.x;
+                st.yacc[slot][2 * q + 1] = acc.y;
+            NDWT_SEND
+        NDWT_SEND
+        if (!emit) return;
+        constexpr int done = ((R - L) % L + L) % L;
+        const int gx = tc.x0 + 4 * (tid - GL);
+        if (tid < GL || tid >= 64 - GR || gx >= a.n1) return;
+        stream_store(reinterpret_cast<v4*>(a.out[0] + obase + (long long)y * a.rs + gx),
+                     v4{st.yacc[done][0], st.yacc[done][1], st.yacc[done][2], st.yacc[done][3]}, a.nt);
+    }
     template <int K, class Exec>
     static NDWT_DEV void step(Exec& ex, State& st, const Taps& tp, const Args& a, const Tile2Coord& tc, long long obase, int y, bool emit, int tid) {
         constexpr int R = (K + 1) % L, S = K % PD;
@@ -2424,10 +2492,13 @@ template <typename T, int L_, int PD_ = 2, int WPE_ = 2> struct Inv2P {
     }
     // one row of a group: threshold, consume, refill the slot with row p + PD (separate passes: neighbouring lanes read this lane's registers)
     template <int K, class Exec>
-    static NDWT_DEV void row(Exec& ex, const Taps& tp, const Args& a, const Tile2Coord& tc, long long ibase, long long obase, int p, int nrows) {
+    static NDWT_DEV void row(Exec& ex, const Taps& tp, const RegT& rt, const Args& a, const Tile2Coord& tc, long long ibase, long long obase, int p, int nrows) {
         const int s = p - (L - 1);
         ex.each([&](int, State& st) __attribute__((always_inline)) { pre<K % PD>(st, a); });
-        ex.each([&](int tid, State& st) __attribute__((always_inline)) { step<K>(ex, st, tp, a, tc, obase, tc.ybeg + s, s >= 0, tid); });
+        ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+            if constexpr (PK) step_pk<K>(ex, st, rt, a, tc, obase, tc.ybeg + s, s >= 0, tid);
+            else step<K>(ex, st, tp, a, tc, obase, tc.ybeg + s, s >= 0, tid);
+        });
         ex.each([&](int, State& st) __attribute__((always_inline)) {
             if (p + PD < nrows) load_row<K % PD>(st, a, ibase, tc.ybeg - LH + p + PD);
         });
@@ -2437,6 +2508,8 @@ template <typename T, int L_, int PD_ = 2, int WPE_ = 2> struct Inv2P {
         const long long ibase = (long long)tc.batch * a.in_bstride;
         const long long obase = (long long)tc.batch * a.out_bstride;
         const int nrows = tc.yend - tc.ybeg + L - 1;
+        RegT rt;
+        load_regt(rt, tp);
         ex.each([&](int tid, State& st) __attribute__((always_inline)) {
             st.off = modn(tc.x0 - 4 * GL + 4 * tid, a.n1);
             NDWT_SFOR(q, PD)
@@ -2446,11 +2519,11 @@ template <typename T, int L_, int PD_ = 2, int WPE_ = 2> struct Inv2P {
         int p = 0;
         for (; p + L <= nrows; p += L) {                  // whole groups: straight-line code, no test per row
             NDWT_SFOR(k, L)
-                row<k>(ex, tp, a, tc, ibase, obase, p + k, nrows);
+                row<k>(ex, tp, rt, a, tc, ibase, obase, p + k, nrows);
             NDWT_SEND
         }
         NDWT_SFOR(k, L - 1)                               // the last, partial group
-            if (p + k < nrows) row<k>(ex, tp, a, tc, ibase, obase, p + k, nrows);
+            if (p + k < nrows) row<k>(ex, tp, rt, a, tc, ibase, obase, p + k, nrows);
         NDWT_SEND
     }
 };

@@ -242,6 +242,16 @@ int emu3(int Lp, int vec4, const T* in, T* out, int n1, int n2, int n3, int nbat
     }
 }
 
+template <class TP> static auto fill_x_pairs(TP& tp, const double* lo, const double* hi, int L, int) -> decltype((void)tp.xplo) {
+    for (int k = 0; k <= L; ++k)
+        for (int h = 0; h < 2; ++h) {
+            const int j = k - h;
+            typedef typename std::remove_reference<decltype(tp.xplo[0][0])>::type E;
+            tp.xplo[k][h] = (j >= 0 && j < L) ? (E)lo[j] : E(0);
+            tp.xphi[k][h] = (j >= 0 && j < L) ? (E)hi[j] : E(0);
+        }
+}
+template <class TP> static void fill_x_pairs(TP&, const double*, const double*, int, long) {}
 template <class K, typename T> int run2(ndwt::Fused2Args<T>& a, const double* lo, const double* hi) {
     typename K::Taps tp;
     for (int ax = 0; ax < 3; ++ax)
@@ -249,6 +259,7 @@ template <class K, typename T> int run2(ndwt::Fused2Args<T>& a, const double* lo
             tp.lo[ax][j] = (T)lo[ax * ndwt::kMaxTaps + j];
             tp.hi[ax][j] = (T)hi[ax * ndwt::kMaxTaps + j];
         }
+    fill_x_pairs(tp, lo, hi, K::L, 0);
     const int nblocks = a.ntx * a.nyc * a.nbatch;
     for (int b = 0; b < nblocks; ++b) {
         typename K::Shared sh;
@@ -505,8 +516,8 @@ extern "C" int ndwt_emu_tpre_f32(int Lp, const float* x, float* out, int n1, int
     return 0;
 }
 // 2-D float synthesis with PD rows of band loads in flight per wave, row loop unrolled in groups of L (Inv2P)
-template <int LL, int PD> static int run_inv2p(ndwt::Fused2Args<float>& a, const double* lo, const double* hi, int ychunk) {
-    typedef ndwt::Inv2P<float, LL, PD, 2> K;
+template <int LL, int PD, bool PK = false> static int run_inv2p(ndwt::Fused2Args<float>& a, const double* lo, const double* hi, int ychunk) {
+    typedef ndwt::Inv2P<float, LL, PD, 2, PK> K;
     ndwt::fused2_geometry(a, K::WX, LL, 64, ychunk);
     return run2<K, float>(a, lo, hi);
 }
@@ -520,6 +531,12 @@ extern "C" int ndwt_emu2_inv2p_f32(int Lp, int depth, const float* in, float* ou
     a.in_bstride = a.out_bstride = vol;
     for (int b = 0; b < 4; ++b) a.in[b] = in + b * vol;
     a.out[0] = out;
+    if (depth == 14) switch (Lp) {   // packed form, 4 rows in flight
+        case 4: return run_inv2p<4, 4, true>(a, lo, hi, ychunk);
+        case 8: return run_inv2p<8, 4, true>(a, lo, hi, ychunk);
+        case 12: return run_inv2p<12, 4, true>(a, lo, hi, ychunk);
+        default: return -1;
+    }
     switch (Lp) {
         case 2: return run_inv2p<2, 2>(a, lo, hi, ychunk);
         case 4: return depth == 4 ? run_inv2p<4, 4>(a, lo, hi, ychunk) : run_inv2p<4, 2>(a, lo, hi, ychunk);

@@ -635,10 +635,10 @@ def test_copy_free_slab_entry_points_and_sharded_driver_on_one_gpu():
     api = importlib.import_module("non-decimated_wavelets_amd.api")
     sh = importlib.import_module("non-decimated_wavelets_amd.sharded")
     n1, n2, n3 = 72, 40, 48
-    # plans on the per-axis path (double with db7 here) refuse the copy-free entry points instead of doing something else
-    p64 = api.Plan([n1, n2, 24], ["db7"] * 3, torch.float64, max_level=1)
+    # plans on the per-axis path (double with db9 here) refuse the copy-free entry points instead of doing something else
+    p64 = api.Plan([n1, n2, 24], ["db9"] * 3, torch.float64, max_level=1)
     assert p64.describe() == "axis"
-    dummy = torch.zeros(8, 24 + 13, n2, n1, device="cuda", dtype=torch.float64)
+    dummy = torch.zeros(8, 24 + 17, n2, n1, device="cuda", dtype=torch.float64)
     with pytest.raises(ndwt.NdwtError):
         p64.synthesis_level_slab_ext([dummy[b].data_ptr() for b in range(8)], dummy.data_ptr(), 1)
     for dtype, tol in ((torch.float32, 2e-6), (torch.float64, 1e-12)):
