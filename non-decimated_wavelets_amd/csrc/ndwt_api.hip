@@ -479,7 +479,7 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     if constexpr (sizeof(T) == 4) {
         // (plane offsets stay below 2^32 bytes: checked there).  A level dilated by 2 on real data is the interleaved-pair form of the
         // kernel (the two x sub-lattices are its (re, im) halves): 512^3 db4 synthesis at tap stride 2 1.52 -> see DESIGN 4.6
-        use_y = inverse && (dil == 1 || (dil == 2 && p->comp == 1 && p->variant_inv != 2)) && inv3y_plan_ok(p, Lp);
+        use_y = inverse && (dil == 1 || ((dil == 2 || dil == 4) && p->comp == 1 && p->variant_inv != 2)) && inv3y_plan_ok(p, Lp);
         if (use_y) { TX = ndwt::inv3y_tx(Lp, ew); TY = ndwt::inv3y_ty(Lp, ew); }
     }
     const int zc_force = p->zchunk_dir[inverse ? 1 : 0] > 0 ? p->zchunk_dir[inverse ? 1 : 0] : p->force_zchunk;
@@ -508,7 +508,8 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     int rc = -1;
     if constexpr (sizeof(T) == 4) {
         if (use_y) {
-            rc = ew == 2 ? launch_inv3yc_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s) : launch_inv3y_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s);
+            rc = ew == 4 ? (vec4 ? launch_inv3y4_f32(a, Lp, variant == 5 ? 1 : 2, td, s) : -1)
+                 : ew == 2 ? launch_inv3yc_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s) : launch_inv3y_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s);
             if (rc == -1) {                               // the geometry above is this kernel's: never fall through to another one with it
                 prof_end(p, s, rc);
                 return fail(NDWT_ERR_UNSUPPORTED, "pair-packed synthesis kernel not instantiated for tap length %d", Lp);

@@ -1348,7 +1348,7 @@ template <typename T, int L> struct Taps3Y {             // the first two member
 // exist only as inputs of the neighbouring lanes' x analysis).
 template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 4, int DEPTH_ = 1, int EW_ = 1, int ZLDS_ = 0, int XH_ = 0> struct Inv3Y {
     static_assert(sizeof(T) == 4, "pair-packed synthesis: float only (v_pk_fma_f32)");
-    static_assert(EW_ == 1 || EW_ == 2, "real or interleaved complex data");
+    static_assert(EW_ == 1 || EW_ == 2 || EW_ == 4, "real data, interleaved complex data / a level dilated by 2, a level dilated by 4");
     static constexpr int L = L_, TX = TX_, TY = TY_, NT = NT_, WPE = WPE_, EW = EW_;
     static constexpr bool VEC4 = VEC4_;
     static constexpr int DEPTH = DEPTH_;                 // register sets of band loads per lane (planes in flight)
@@ -1398,7 +1398,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
     // in registers: as loads from constant memory it re-issues them (s_load + lgkmcnt(0)) inside every band of the x stage.
     struct RegTaps {
         v2 xp[EW == 1 ? L + 1 : 1];   // (lo_x[k], lo_x[k-1]); real data only
-        v2 xl[EW == 2 ? L / 2 : 1];   // (lo_x[2m], lo_x[2m+1]); complex data only
+        v2 xl[EW != 1 ? L / 2 : 1];   // (lo_x[2m], lo_x[2m+1]); EW = 2, 4 (one tap per pair of scalars)
         v2 yl[L / 2], zl[L / 2];      // (lo[2m], lo[2m+1]) of the y and z axes
     };
     static NDWT_DEV v2 pinned(v2 t) {
@@ -1560,7 +1560,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
         if (a.shrink_mask == 0) return;
         NDWT_SFOR(k, NRND)
             NDWT_SFOR(b, 8)
-                if ((a.shrink_mask >> b) & 1) shrink4<T, EW>(st.raw[SET][k][b], a.shrink_thr, a.shrink_hard);
+                if ((a.shrink_mask >> b) & 1) shrink4<T, (EW == 2 ? 2 : 1)>(st.raw[SET][k][b], a.shrink_thr, a.shrink_hard);
             NDWT_SEND
         NDWT_SEND
     }
@@ -1590,7 +1590,9 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
                             constexpr bool ua23 = ka - 2 >= 0 && ka - 2 <= L, ub23 = kb - 2 >= 0 && kb - 2 <= L;
                             constexpr int jc0 = m - 2 * GL + LH, jc1 = jc0 - 1;             // EW = 2: taps of the lane's two elements
                             constexpr bool c0ok = jc0 >= 0 && jc0 < L, c1ok = jc1 >= 0 && jc1 < L;
-                            if constexpr (EW == 1 ? (ua01 || ub01 || ua23 || ub23) : (c0ok || c1ok)) {
+                            constexpr int j4 = D + LH;                                      // EW = 4: the lane D away is x element D away
+                            constexpr bool ok4 = j4 >= 0 && j4 < L;
+                            if constexpr (EW == 1 ? (ua01 || ub01 || ua23 || ub23) : EW == 2 ? (c0ok || c1ok) : ok4) {
                                 const v2 w = {NDWT_LANE_SHIFT(ex, tid, D, s.raw[SET][k][xb + 2 * yb + 4 * zb][c]),
                                               NDWT_LANE_SHIFT(ex, tid, D, s.raw[SET][k][xb + 2 * yb + 4 * zb][c + 1])};
                                 if constexpr (EW == 1) {
@@ -1598,10 +1600,14 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
                                     if constexpr (ub01) xtap<1, kb, xb == 1>(acc[zb][0], w, tp);
                                     if constexpr (ua23) xtap<0, ka - 2, xb == 1>(acc[zb][1], w, tp);
                                     if constexpr (ub23) xtap<1, kb - 2, xb == 1>(acc[zb][1], w, tp);
-                                } else {
+                                } else if constexpr (EW == 2) {
                                     // w = window element m - 2 GL (re, im); it feeds the lane's element e through tap m - 2 GL - e + LH
                                     if constexpr (c0ok) tap_fma<jc0 < 0 ? 0 : (jc0 >= L ? 0 : jc0), xb == 1>(acc[zb][0], w, tp.xl);
                                     if constexpr (c1ok) tap_fma<jc1 < 0 ? 0 : (jc1 >= L ? 0 : jc1), xb == 1>(acc[zb][1], w, tp.xl);
+                                } else {
+                                    // a level dilated by 4: the lane's 4 scalars are the same x of 4 sub-lattices, the lane D away holds the
+                                    // element D steps away on each of them -- whole-lane shifts, one tap for both pairs
+                                    tap_fma<j4 < 0 ? 0 : (j4 >= L ? 0 : j4), xb == 1>(acc[zb][c / 2], w, tp.xl);
                                 }
                             }
                         NDWT_SEND

@@ -28,6 +28,7 @@ int launch_inv3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4,
 // threads; depth = register sets of band loads (2: staggered refill, aligned volumes only)
 int launch_inv3y_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, const void* taps_dev, hipStream_t s);
 int launch_inv3yc_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, const void* taps_dev, hipStream_t s);   // interleaved complex
+int launch_inv3y4_f32(const Fused3Args<float>& a, int Lp, int depth, const void* taps_dev, hipStream_t s);   // a level dilated by 4 (EW = 4), vec4 rows
 
 // level 1 of a denoising step in one launch (Den3: in[0] = x, in[1] = approximation band) and the approximation-only analysis
 // that goes with it (tall 64 x 32 tile); float, real data, tap lengths 2 .. 8: ndwt_fused3_f32_den.hip

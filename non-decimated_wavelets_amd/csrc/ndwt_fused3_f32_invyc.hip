@@ -28,4 +28,21 @@ int launch_inv3yc_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, 
         default: return -1;
     }
 }
+
+// a level dilated by 4 on real data (EW = 4): rows of whole groups of 4 scalars only
+template <int LL, int DEPTH> static int go4(const Fused3Args<float>& a, const void* taps_dev, hipStream_t s) {
+    typedef Inv3Y<float, LL, inv3y_tx(LL, 4), inv3y_ty(LL, 4), 1024, true, 4, DEPTH, 4> K;
+    FusedTapsD unused;
+    unused.Lp = LL;
+    return launch_fused3<K>(a, unused, taps_dev, s);
+}
+int launch_inv3y4_f32(const Fused3Args<float>& a, int Lp, int depth, const void* taps_dev, hipStream_t s) {
+    switch (Lp) {
+        case 2: return depth == 2 ? go4<2, 2>(a, taps_dev, s) : go4<2, 1>(a, taps_dev, s);
+        case 4: return go4<4, 1>(a, taps_dev, s);
+        case 6: return go4<6, 1>(a, taps_dev, s);
+        case 8: return depth == 2 ? go4<8, 2>(a, taps_dev, s) : go4<8, 1>(a, taps_dev, s);
+        default: return -1;
+    }
+}
 }  // namespace ndwt

@@ -19,6 +19,7 @@ int emu_y_small(int depth, int Lp, int vec4, ndwt::Fused3Args<float>& a, const d
 int emu_y_small2(int Lp, int vec4, ndwt::Fused3Args<float>& a, const double* lo, const double* hi);
 int emu_y_prod(int depth, int Lp, int vec4, ndwt::Fused3Args<float>& a, const double* lo, const double* hi);
 int emu_yc_small(int depth, int Lp, int vec4, ndwt::Fused3Args<float>& a, const double* lo, const double* hi);
+int emu_y_dilated(int ew, int depth, int Lp, ndwt::Fused3Args<float>& a, const double* lo, const double* hi);
 
 namespace {
 
@@ -172,6 +173,10 @@ int emu3(int Lp, int vec4, const T* in, T* out, int n1, int n2, int n3, int nbat
             typedef ndwt::Fused3Tile<T, false, 1> DF;
             typedef ndwt::Fused3Tile<T, true, 4> DI;
             if constexpr (INV) {
+                if ((variant == 5 || variant == 8) && vec4 && Lp <= 8) {   // the pair-packed kernel on whole-lane x shifts (EW = 4), production tiles
+                    geometry(ndwt::inv3y_tx(Lp, 4), ndwt::inv3y_ty(Lp, 4));
+                    return emu_y_dilated(4, variant == 5 ? 1 : 2, Lp, a, lo, hi);
+                }
                 geometry(DI::TX, DI::TY);
                 return dispatch<T, ndwt::Inv3S, DI::TX, DI::TY, DI::NT, DI::RY, false, 4>(Lp, vec4, a, lo, hi);
             } else {
@@ -186,6 +191,12 @@ int emu3(int Lp, int vec4, const T* in, T* out, int n1, int n2, int n3, int nbat
             if ((variant == 5 || variant == 8) && small_tile && Lp <= 12) {
                 geometry(16, 8);
                 return emu_yc_small(variant == 5 ? 1 : 2, Lp, vec4, a, lo, hi);
+            }
+        }
+        if constexpr (INV && sizeof(T) == 4) {   // a level dilated by 2 on the production tile of the pair-packed kernel's interleaved form
+            if ((variant == 5 || variant == 8) && !small_tile && vec4 && dil == 2 && (Lp == 4 || Lp == 8)) {
+                geometry(ndwt::inv3y_tx(Lp, 2), ndwt::inv3y_ty(Lp, 2));
+                return emu_y_dilated(2, variant == 5 ? 1 : 2, Lp, a, lo, hi);
             }
         }
         if (small_tile) {
@@ -429,6 +440,29 @@ int emu_y_prod(int depth, int Lp, int vec4, ndwt::Fused3Args<float>& a, const do
 int emu_yc_small(int depth, int Lp, int vec4, ndwt::Fused3Args<float>& a, const double* lo, const double* hi) {
     return depth == 1 ? dispatchY<float, 16, 8, 128, true, 1, 2>(Lp, vec4, a, lo, hi)
                       : dispatchY<float, 16, 8, 512, true, 2, 2>(Lp, vec4, a, lo, hi);
+}
+#endif
+
+#if EMU_IN(15)
+// dilated levels through the pair-packed synthesis kernel: EW = 2 (its interleaved-pair form) and EW = 4 (whole-lane x shifts), production tiles
+template <int LL, int EWV, int D> static int run_yd(ndwt::Fused3Args<float>& a, const double* lo, const double* hi) {
+    return runY<ndwt::Inv3Y<float, LL, ndwt::inv3y_tx(LL, EWV), ndwt::inv3y_ty(LL, EWV), 1024, true, 2, D, EWV>, float>(a, lo, hi);
+}
+int emu_y_dilated(int ew, int depth, int Lp, ndwt::Fused3Args<float>& a, const double* lo, const double* hi) {
+    if (ew == 2) {
+        switch (Lp) {
+            case 4: return run_yd<4, 2, 1>(a, lo, hi);
+            case 8: return depth == 2 ? run_yd<8, 2, 2>(a, lo, hi) : run_yd<8, 2, 1>(a, lo, hi);
+            default: return -1;
+        }
+    }
+    switch (Lp) {
+        case 2: return depth == 2 ? run_yd<2, 4, 2>(a, lo, hi) : run_yd<2, 4, 1>(a, lo, hi);
+        case 4: return run_yd<4, 4, 1>(a, lo, hi);
+        case 6: return run_yd<6, 4, 1>(a, lo, hi);
+        case 8: return depth == 2 ? run_yd<8, 4, 2>(a, lo, hi) : run_yd<8, 4, 1>(a, lo, hi);
+        default: return -1;
+    }
 }
 #endif
 

@@ -410,6 +410,29 @@ def test_emulated_dilated_level_on_sublattices(emu, sizes, wn, dil, dtype):
 
 
 @pytest.mark.slow
+@pytest.mark.parametrize("sizes,wn,dil", [
+    ((136, 68, 6), ("db4", "db4", "db4"), 2),          # 68 x 34 per sub-lattice: ragged production tiles
+    ((72, 16, 8), ("db2", "db2", "db2"), 2),
+    ((264, 104, 8), ("db4", "db2", "db4"), 4),         # 8 taps at stride 4: 64 x 24 tiles, 23 lanes per haloed row
+    ((72, 16, 8), ("db2", "db2", "db2"), 4),
+    ((64, 12, 16), ("db3", "db1", "db3"), 4),
+    ((80, 8, 12), ("db1", "db1", "db1"), 4),
+])
+def test_emulated_dilated_synthesis_on_the_pair_packed_kernel(emu, sizes, wn, dil):
+    """float synthesis of an a-trous level through Inv3Y: tap stride 2 = its interleaved-pair form (the two x sub-lattices are the
+    (re, im) halves), tap stride 4 = whole-lane x shifts (EW = 4, one tap for both pairs of a lane); one and two register sets"""
+    rng = np.random.default_rng(24)
+    c = rng.standard_normal(tuple(sizes) + (8,))
+    filt = [orc.wave_filters(w) for w in wn]
+    want = orc.spatial_level_rec(c, filt, 1, dil)
+    L = max(len(f[0]) for f in filt)
+    for variant in ((5, 8) if L in (2, 8) else (5,)):
+        got = _run(emu, c, wn, 1, True, np.float32, True, 0, False, variant=variant, dil=dil)
+        assert np.isfinite(got).all(), variant
+        assert np.abs(got - want).max() <= 2e-6 * max(np.abs(want).max(), 1.0), variant
+
+
+@pytest.mark.slow
 @pytest.mark.parametrize("sizes,wn,dtype", [((72, 20), ("db4", "db2"), np.float64), ((264, 14), ("db2", "db4"), np.float32)])
 def test_emulated_dilated_2d_level_on_row_sublattices(emu, sizes, wn, dtype):
     """2-D a-trous level with tap stride 2: x through EW = 2, the two row sub-lattices as batch items (row stride 2*n1)"""

@@ -11,7 +11,7 @@ api = importlib.import_module("non-decimated_wavelets_amd.api")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 wname = sys.argv[2] if len(sys.argv) > 2 else "db4"
 mode = sys.argv[3] if len(sys.argv) > 3 else "atrous"
-plan = api.Plan([n, n, n], [wname] * 3, torch.float32, False, True, mode, max_level=3)
+plan = api.Plan([n, n, n], [wname] * 3, torch.float32, False, True, mode, max_level=3).set_variant_from_env()
 x = torch.randn(n, n, n, device="cuda")
 y = torch.empty((api.num_bands(3, 3), n, n, n), device="cuda")
 r = torch.empty_like(x)
