@@ -90,7 +90,8 @@ int ndwt_plan_describe(const ndwt_plan* plan, char* buf, int buflen);
  * outer-axis planes per workgroup; 0 restores the default.  Results never depend on it. */
 int ndwt_plan_set_tuning(ndwt_plan* plan, int target_blocks, int force_zchunk);
 /* test / tuning hook of tools/ (interleaved A/B runs): kernel variant per direction, marched chunk per direction, fp64 on the
- * fused (1) or per-axis (0) kernels.  Negative = leave unchanged.  Every variant computes the same values; the library never
+ * fused (1) or per-axis (0) kernels.  Negative = leave unchanged.  Every variant computes the same transform (bit-identical where
+ * only the schedule differs; to rounding where the order of the FMAs does: packed / scalar forms, kernel families); the library never
  * reads the environment. */
 int ndwt_plan_set_variant(ndwt_plan* plan, int variant_fwd, int variant_inv, int zchunk_fwd, int zchunk_inv, int fp64_fused);
 /* test / tuning hook: 0 makes ndwt_denoise keep the level-1 detail bands in memory (dec, thresholding fused into the synthesis
