@@ -294,14 +294,15 @@ static bool fused3_eligible(const ndwt_plan* p, long long stride, int* Lp_out, i
     if (p->dtype == NDWT_F64 && !p->fp64_fused) return false;
     int Lp = 2;
     for (int a = 0; a < 3; ++a) Lp = p->filt[a].len > Lp ? p->filt[a].len : Lp;
-    const int lmax = p->complexity != NDWT_REAL ? 12 : (p->dtype == NDWT_F32 ? (dir == 0 ? 20 : 16) : 16);
+    const int lmax = p->complexity != NDWT_REAL ? (p->dtype == NDWT_F32 && dir == 0 ? 16 : 12) : (p->dtype == NDWT_F32 ? (dir == 0 ? 20 : 16) : 16);
     // 18- and 20-tap synthesis exist as the pair-packed kernel only (uniform wavelets, or mixed ones with even padding on every axis)
     if (Lp > lmax && !(dir == 1 && Lp <= 20 && inv3y_plan_ok(p, Lp))) return false;
     if (p->dtype == NDWT_F64 && Lp > 16) return false;   // double: up to db8 (64x8 tiles with 512 threads keep 10 .. 16 taps in 256 registers)
     // interleaved complex: the fused kernels with the x taps stepping over (re, im) pairs, tap lengths <= 8 (float: <= 12); rows of an
     // odd number of elements run the VEC4 = false instances (one access per lane wherever its 4 scalars are contiguous)
     // (complex128: 10 taps both ways, 12 taps analysis only -- its synthesis spills 500+ registers on every tile)
-    if (p->complexity != NDWT_REAL && Lp > (p->dtype == NDWT_F32 ? 12 : (dir == 0 ? 12 : 10))) return false;
+    // (complex64: 14 / 16 taps in the analysis, and in the synthesis through the pair-packed kernel -- the Lp > lmax clause above)
+    if (p->complexity != NDWT_REAL && Lp > (p->dtype == NDWT_F32 ? 16 : (dir == 0 ? 12 : 10))) return false;
     long long nbatch = p->ndim == 4 ? p->dims[3] + 64 : 1;
     if (!fused3_fits(p->dims[0] * p->comp, p->dims[1], p->dims[2] + 64, nbatch)) return false;
     *Lp_out = Lp;
@@ -391,7 +392,7 @@ void fused3_tile_shape(bool f64, bool inverse, int variant, int Lp, int* TX, int
 // signs), which holds for the zero-padded taps of an axis when its padding (Lp - len) / 2 is even; it keeps plane offsets in
 // 32-bit BYTE counts.  variant_inv 4 forces the older lane-shift kernel (Inv3S) for A/B runs.
 static bool inv3y_plan_ok(const ndwt_plan* p, int Lp) {
-    if (p->dtype != NDWT_F32 || Lp > (p->comp == 1 ? 20 : 12) || p->variant_inv == 3 || p->variant_inv == 4) return false;
+    if (p->dtype != NDWT_F32 || Lp > (p->comp == 1 ? 20 : 16) || p->variant_inv == 3 || p->variant_inv == 4) return false;
     for (int ax = 0; ax < 3; ++ax)
         if (((Lp - p->filt[ax].len) / 2) % 2 != 0) return false;
     return p->dims[0] * p->comp * p->dims[1] < (1LL << 30);

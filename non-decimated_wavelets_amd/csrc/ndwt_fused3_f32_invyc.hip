@@ -1,4 +1,4 @@
-// fused 3-D inv level, float, interleaved complex data, stride 1: the pair-packed lane-shift kernel (Inv3Y, EW = 2), tap lengths 2..12
+// fused 3-D inv level, float, interleaved complex data, stride 1: the pair-packed lane-shift kernel (Inv3Y, EW = 2), tap lengths 2..16
 #include "ndwt_fused_kernels.h"
 namespace ndwt {
 
@@ -25,6 +25,8 @@ int launch_inv3yc_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, 
         NDWT_INVYC_CASE(8, true)
         NDWT_INVYC_CASE(10, false)   // (two register sets: 1 spilled register)
         NDWT_INVYC_CASE(12, false)
+        NDWT_INVYC_CASE(14, false)   // 48-wide tiles (ndwt_fused_tile.h)
+        NDWT_INVYC_CASE(16, false)
         default: return -1;
     }
 }

@@ -179,6 +179,8 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
             NDWT_FUSED_CASE_C(Fwd3, false, T, 8, 0)                       \
             NDWT_FUSED_CASE_C(Fwd3, false, T, 10, 1)                      \
             NDWT_FUSED_CASE_C(Fwd3, false, T, 12, 1)                      \
+            NDWT_FUSED_CASE_C(Fwd3, false, T, 14, 1)                      \
+            NDWT_FUSED_CASE_C(Fwd3, false, T, 16, 1)                      \
             default: return -1;                                           \
         }                                                                 \
     }                                                                     \

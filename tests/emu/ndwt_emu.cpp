@@ -187,8 +187,8 @@ int emu3(int Lp, int vec4, const T* in, T* out, int n1, int n2, int n3, int nbat
         return -1;
     }
     if (ew == 2) {      // interleaved complex: n1 counts scalars; lane-shift synthesis and LDS analysis kernels
-        if constexpr (INV && sizeof(T) == 4) {   // pair-packed synthesis on (re, im) pairs: small tile, every tap length up to 12
-            if ((variant == 5 || variant == 8) && small_tile && Lp <= 12) {
+        if constexpr (INV && sizeof(T) == 4) {   // pair-packed synthesis on (re, im) pairs: small tile, every tap length up to 16
+            if ((variant == 5 || variant == 8) && small_tile && Lp <= 16) {
                 geometry(16, 8);
                 return emu_yc_small(variant == 5 ? 1 : 2, Lp, vec4, a, lo, hi);
             }

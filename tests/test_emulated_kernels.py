@@ -148,6 +148,9 @@ CASES_YC = [
     ((20, 15, 13), ("db6", "db6", "db6"), True, 6),              # 6 halo groups of two elements each
     ((13, 12, 12), ("db6", "db2", "db4"), False, 0),
     ((67, 35, 8), ("db4", "db4", "db4"), False, 0),              # 134 scalars per row: the last lane of a row straddles the wrap
+    ((22, 17, 15), ("db7", "db7", "db7"), True, 0),              # 14 / 16 taps (fused for complex64 since round 3)
+    ((24, 18, 17), ("db8", "db6", "db4"), True, 7),
+    ((21, 16, 16), ("db8", "db8", "db8"), False, 0),
 ]
 
 

@@ -488,7 +488,11 @@ def test_long_filters_double(sizes, wn, path):
     ([32, 24, 20], "db5", "single", "fused3d"),
     ([34, 21, 19], "db6", "single", "fused3d"),
     ([32, 24, 20], ["db6", "db2", "db5"], "single", "fused3d"),
-    ([32, 24, 20], "db7", "single", "axis"),
+    ([32, 24, 20], "db7", "single", "fused3d"),                        # complex64 with 14 / 16 taps: 64x16 analysis tile, 48-wide pair-packed synthesis
+    ([50, 37, 20], "db8", "single", "fused3d"),
+    ([33, 24, 20], "db8", "single", "fused3d"),                        # ... odd number of complex elements per row
+    ([32, 24, 20], ["db8", "db7", "db8"], "single", "fused3d analysis, axis synthesis"),   # odd padding: no derived high-pass taps
+    ([32, 24, 20], "db9", "single", "axis"),
     ([32, 24, 20], "db5", "double", "fused3d"),                        # complex128: fused up to 10 taps,
     ([34, 21, 19], "db5", "double", "fused3d"),
     ([32, 24, 20], "db6", "double", "fused3d analysis, axis synthesis"),   # ... 12 taps in the analysis only

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""dec+rec time of interleaved complex64 volumes for db4 .. db6, fused vs per-axis.  python tools/bench_complex_long.py [n]"""
+"""dec+rec time of interleaved complex64 volumes for db4 .. db8, fused vs per-axis.  python tools/bench_complex_long.py [n] [orders]"""
 import importlib
 import sys
 import time
@@ -10,7 +10,7 @@ sys.path.insert(0, ".")
 api = importlib.import_module("non-decimated_wavelets_amd.api")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 level = 3
-for K in (4, 5, 6):
+for K in ([int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else (4, 5, 6, 7, 8)):
     for generic in (False, True):
         plan = api.Plan([n, n, n], [f"db{K}"] * 3, torch.float32, True, True, "reference", max_level=level).set_variant_from_env()
         plan.set_path(generic)
