@@ -584,7 +584,7 @@ static int fused2_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     // Depth 4 runs in the packed form (pairs of adjacent x outputs per v_pk_fma_f32, tap pairs pinned in SGPRs; variant_inv 7 = scalar FMAs):
     // 4096^2 db4 74 us either way (the kernel sits on its memory floor), db6 116 -> 98 us, 2048^2 db4 27.1 -> 25.1 us per level.
     const int tiles2 = (a.n1 + fused2_tile_width(inverse, Lp, ew2) - 1) / fused2_tile_width(inverse, Lp, ew2);
-    const bool deep = inverse && sizeof(T) == 4 && ew2 == 1 && dil == 1 && vec4 && p->variant_inv != 1 && n2 >= 64 &&
+    const bool deep = inverse && (sizeof(T) == 4 || Lp <= 8) && ew2 == 1 && dil == 1 && vec4 && p->variant_inv != 1 && n2 >= 64 &&
                       ((long long)tiles2 * ((n2 + 69) / 70) <= 1280 || p->variant_inv >= 2);
     const int pdepth = (p->variant_inv == 2 || p->variant_inv == 6) ? 2 : 4;
     const int waves = (deep && p->variant_inv != 2 && p->variant_inv != 4) ? 1024 : 2048;
@@ -597,6 +597,8 @@ static int fused2_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     int rc = -1;
     if constexpr (sizeof(T) == 4) {
         if (deep) rc = launch_inv2p_f32(a, Lp, pdepth, td, s, p->variant_inv != 7);
+    } else {
+        if (deep) rc = launch_inv2p_f64(a, Lp, td, s);
     }
     if (rc == -1) rc = launch2<T>(inverse, a, Lp, vec4, ew2, td, s);
     prof_end(p, s, rc);

@@ -1064,6 +1064,27 @@ def test_dec_rec_and_denoise_are_graph_capturable(d, sizes, wn, precision):
     assert torch.equal(y, yg) and torch.equal(r, rg) and torch.equal(den, dg)
 
 
+@pytest.mark.parametrize("sizes,wn,precision", [([260, 96], "db4", "double"), ([512, 70], ["db2", "db3"], "double"), ([248, 64], "db1", "double"),
+                                                ([264, 130], "db6", "single"), ([256, 64], ["db2", "db2"], "single")])
+def test_2d_synthesis_with_rows_in_flight(sizes, wn, precision):
+    """Inv2P on the device: double (2 / 4 rows of band loads in flight, up to 8 taps) and the packed float form (4 / 8 / 12 taps) against
+    the oracle, and denoise (thresholding fused into those loads) against the separate pass"""
+    rng = np.random.default_rng(11)
+    wl = [wn] * 2 if isinstance(wn, str) else wn
+    c = rng.standard_normal(sizes + [7])
+    w = ndwt.nd_dwt_2D(wn, sizes, "pres_l2_norm", 1, "precision", precision)
+    got = w.rec(_colmajor_gpu(c, precision)).cpu().numpy()
+    want = orc.spatial_rec(c, wl, 1)
+    assert np.abs(got - want).max() <= TOL[precision] * max(np.abs(want).max(), np.abs(c).max())
+    x = rng.standard_normal(sizes)
+    xg = _colmajor_gpu(x, precision)
+    y = w.dec(xg, 2)
+    assert _relerr(w.rec(y).cpu().numpy(), x) < (1e-13 if precision == "double" else 1e-5)
+    den = w.denoise(xg, 2, 0.4, "soft")
+    ref = w.rec(w.shrink(y.clone(), 0.4, "soft"))
+    assert float((den - ref).abs().max()) <= 20 * TOL[precision] * max(float(ref.abs().max()), 1.0)
+
+
 def test_sharded_driver_band_pitch_option():
     """ShardedNdDwt(band_pitch='packed') returns a contiguous coefficient slab (for callers that pass it to collectives or take raw
     pointers); the default 'auto' returns the pitched view; the values are the same"""

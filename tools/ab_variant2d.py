@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B of variants (Plan.set_variant) of the fused 2-D path: 3 levels of dec, rec and dec+rec on an n x n fp32 image, timed
 round-robin in one process; the reconstruction compared with the first variant's.
-python tools/ab_variant2d.py 0,7 [wname] [n] [fwd|inv|both]   (which direction the variant number applies to; default inv)"""
+python tools/ab_variant2d.py 0,7 [wname] [n] [fwd|inv|both] [f32|f64]   (which direction the variant number applies to; default inv)"""
 import importlib
 import sys
 
@@ -13,14 +13,15 @@ variants = [int(v) for v in sys.argv[1].split(",")]
 wname = sys.argv[2] if len(sys.argv) > 2 else "db4"
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 which = sys.argv[4] if len(sys.argv) > 4 else "inv"
+dt = torch.float64 if len(sys.argv) > 5 and sys.argv[5] == "f64" else torch.float32
 level = 3
 plans = {}
 for v in variants:
-    plans[v] = api.Plan([n, n], [wname] * 2, torch.float32, False, True, "reference", max_level=level)
+    plans[v] = api.Plan([n, n], [wname] * 2, dt, False, True, "reference", max_level=level)
     plans[v].set_variant(fwd=v if which in ("fwd", "both") else -1, inv=v if which in ("inv", "both") else -1)
-x = torch.randn(n, n, device="cuda")
-y = torch.empty(api.num_bands(2, level), n, n, device="cuda")
-r = {v: torch.empty(n, n, device="cuda") for v in variants}
+x = torch.randn(n, n, device="cuda", dtype=dt)
+y = torch.empty(api.num_bands(2, level), n, n, device="cuda", dtype=dt)
+r = {v: torch.empty(n, n, device="cuda", dtype=dt) for v in variants}
 s = torch.cuda.current_stream().cuda_stream
 for v in variants:
     plans[v].dec(x.data_ptr(), y.data_ptr(), level, s)
