@@ -1,35 +1,14 @@
-// fused 2-D levels, float
+// fused 2-D levels, float: analysis (Fwd2S) and the dispatch of the synthesis kernels (their instances: ndwt_fused2_f32_{inva,invb,invp}.hip)
 #include "ndwt_fused_kernels.h"
 namespace ndwt {
+int launch_fwd2_f32_long(const Fused2Args<float>& a, int Lp, bool vec4, int ew, const void* taps_dev, hipStream_t s);
+int launch_inv2_f32_short(const Fused2Args<float>& a, int Lp, bool vec4, int ew, const void* taps_dev, hipStream_t s);
+int launch_inv2_f32_long(const Fused2Args<float>& a, int Lp, bool vec4, int ew, const void* taps_dev, hipStream_t s);
 int launch_fwd2_f32(const Fused2Args<float>& a, int Lp, bool vec4, int ew, const void* taps_dev, hipStream_t s) {
-    NDWT_FUSED2_SWITCH(Fwd2S, float)
+    if (Lp > 6) return launch_fwd2_f32_long(a, Lp, vec4, ew, taps_dev, s);
+    NDWT_FUSED2_SWITCH_SHORT(Fwd2S, float)
 }
 int launch_inv2_f32(const Fused2Args<float>& a, int Lp, bool vec4, int ew, const void* taps_dev, hipStream_t s) {
-    NDWT_FUSED2_SWITCH(Inv2S, float)
-}
-
-// float synthesis of real data, rows of whole groups of 4 scalars: PD rows of band loads in flight per wave, the row loop unrolled in
-// groups of L (Inv2P); 2 waves per SIMD (the 256-register budget)
-template <int LL, int PD, bool PK = false> static int go_p(const Fused2Args<float>& a, const void* taps_dev, hipStream_t s) {
-    return launch_fused2<Inv2P<float, LL, PD, 2, PK>>(a, taps_dev, s);
-}
-int launch_inv2p_f32(const Fused2Args<float>& a, int Lp, int depth, const void* taps_dev, hipStream_t s, int packed) {
-    if (packed && depth == 4) {      // packed FMAs on pairs of adjacent x outputs, tap pairs pinned in SGPRs
-        switch (Lp) {
-            case 4: return go_p<4, 4, true>(a, taps_dev, s);
-            case 8: return go_p<8, 4, true>(a, taps_dev, s);
-            case 12: return go_p<12, 4, true>(a, taps_dev, s);
-            default: break;
-        }
-    }
-    switch (Lp) {
-        case 2: return go_p<2, 2>(a, taps_dev, s);
-        case 4: return depth == 4 ? go_p<4, 4>(a, taps_dev, s) : go_p<4, 2>(a, taps_dev, s);
-        case 6: return go_p<6, 2>(a, taps_dev, s);
-        case 8: return depth == 4 ? go_p<8, 4>(a, taps_dev, s) : go_p<8, 2>(a, taps_dev, s);
-        case 10: return go_p<10, 2>(a, taps_dev, s);
-        case 12: return depth == 4 ? go_p<12, 4>(a, taps_dev, s) : go_p<12, 2>(a, taps_dev, s);
-        default: return -1;
-    }
+    return Lp > 6 ? launch_inv2_f32_long(a, Lp, vec4, ew, taps_dev, s) : launch_inv2_f32_short(a, Lp, vec4, ew, taps_dev, s);
 }
 }  // namespace ndwt

@@ -1,11 +1,9 @@
-// fused 2-D levels, double
+// fused 2-D levels, double: analysis (Fwd2S) and the rows-in-flight synthesis (Inv2P); Inv2S: ndwt_fused2_f64_inv.hip
 #include "ndwt_fused_kernels.h"
 namespace ndwt {
 int launch_fwd2_f64(const Fused2Args<double>& a, int Lp, bool vec4, int ew, const void* taps_dev, hipStream_t s) {
-    NDWT_FUSED2_SWITCH(Fwd2S, double)
-}
-int launch_inv2_f64(const Fused2Args<double>& a, int Lp, bool vec4, int ew, const void* taps_dev, hipStream_t s) {
-    NDWT_FUSED2_SWITCH(Inv2S, double)
+    if (Lp > 6) { NDWT_FUSED2_SWITCH_LONG(Fwd2S, double) }
+    NDWT_FUSED2_SWITCH_SHORT(Fwd2S, double)
 }
 // double synthesis of real data, rows of whole groups of 4 scalars: rows of band loads in flight, the row loop unrolled in groups of L
 // (Inv2P); up to 8 taps fit the 256-register budget without spills (4 rows in flight with 4 taps, 2 otherwise)

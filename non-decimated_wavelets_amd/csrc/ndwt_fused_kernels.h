@@ -56,11 +56,16 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
             return vec4 ? launch_fused2<KIND<T, LL, true, (sizeof(T) == 8 ? 2 : 4), 2>>(a, taps_dev, s)   \
                         : launch_fused2<KIND<T, LL, false, (sizeof(T) == 8 ? 2 : 4), 2>>(a, taps_dev, s); \
         return vec4 ? launch_fused2<KIND<T, LL, true, (sizeof(T) == 8 ? 2 : 4)>>(a, taps_dev, s) : launch_fused2<KIND<T, LL, false, (sizeof(T) == 8 ? 2 : 4)>>(a, taps_dev, s);
-#define NDWT_FUSED2_SWITCH(KIND, T)   \
+// (the tap lengths are split over two translation units per kernel family: one unit with all of them is the long pole of the build)
+#define NDWT_FUSED2_SWITCH_SHORT(KIND, T) \
     switch (Lp) {                     \
         NDWT_FUSED2_CASE(KIND, T, 2)  \
         NDWT_FUSED2_CASE(KIND, T, 4)  \
         NDWT_FUSED2_CASE(KIND, T, 6)  \
+        default: return -1;           \
+    }
+#define NDWT_FUSED2_SWITCH_LONG(KIND, T) \
+    switch (Lp) {                     \
         NDWT_FUSED2_CASE(KIND, T, 8)  \
         NDWT_FUSED2_CASE(KIND, T, 10) \
         NDWT_FUSED2_CASE(KIND, T, 12) \
@@ -97,7 +102,7 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
 // kernel Inv3S on a tall 64x32 tile (1024 threads, one workgroup per CU; db6: 512 threads with two items each -- the 1024-thread
 // form spills there) for mixed wavelets with odd tap padding, dilated levels and NDWT_VARIANT_INV=4; variant 3 = the LDS kernel
 // (A/B, db4 only)
-#define NDWT_FUSED_SWITCH_INV_F32(T)                                      \
+#define NDWT_FUSED_SWITCH_INV_F32_EW(T)                                      \
     if (ew == 4) {                                                        \
         switch (t.Lp) {                                                   \
             NDWT_FUSED_CASE_E(Inv3S, true, T, 2, 4, 4)                    \
@@ -117,7 +122,8 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
             NDWT_FUSED_CASE_C(Inv3S, true, T, 12, 2)                      \
             default: return -1;                                           \
         }                                                                 \
-    }                                                                     \
+    }
+#define NDWT_FUSED_SWITCH_INV_F32_REAL(T)                                 \
     if (variant == 3 && t.Lp == 8) { switch (t.Lp) { NDWT_FUSED_CASE(Inv3, true, T, 8, 3) } }   \
     switch (t.Lp) {                                                       \
         NDWT_FUSED_CASE(Inv3S, true, T, 2, 1)                             \
