@@ -341,7 +341,7 @@ static bool fused2_dilated_eligible(const ndwt_plan* p, long long stride, int* L
 static bool fused2_eligible(const ndwt_plan* p, long long stride, int* Lp_out) {
     if (p->path != NDWT_PATH_AUTO || stride != 1 || p->ndim != 2) return false;
     int Lp = p->filt[0].len > p->filt[1].len ? p->filt[0].len : p->filt[1].len;
-    if (Lp > 12) return false;
+    if (Lp > (p->dtype == NDWT_F32 && p->complexity == NDWT_REAL ? 20 : 12)) return false;   // float real: db7 .. db10 on the 256-register budget
     if (p->complexity != NDWT_REAL && Lp > 8) return false;
     if (p->dims[0] >= (1LL << 30) || p->dims[1] >= (1LL << 30)) return false;
     *Lp_out = Lp;
@@ -548,6 +548,7 @@ int fused2_tile_width(bool inverse, int Lp, int ew) {
 
 template <typename T> static int launch2(bool inverse, const Fused2Args<T>& a, int Lp, bool vec4, int ew, const void* td, hipStream_t s);
 template <> int launch2<float>(bool inverse, const Fused2Args<float>& a, int Lp, bool vec4, int ew, const void* td, hipStream_t s) {
+    if (Lp > 12) return ew != 1 ? -1 : (inverse ? launch_inv2_f32_14to20(a, Lp, vec4, td, s) : launch_fwd2_f32_14to20(a, Lp, vec4, td, s));
     return inverse ? launch_inv2_f32(a, Lp, vec4, ew, td, s) : launch_fwd2_f32(a, Lp, vec4, ew, td, s);
 }
 template <> int launch2<double>(bool inverse, const Fused2Args<double>& a, int Lp, bool vec4, int ew, const void* td, hipStream_t s) {
@@ -584,7 +585,7 @@ static int fused2_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     // Depth 4 runs in the packed form (pairs of adjacent x outputs per v_pk_fma_f32, tap pairs pinned in SGPRs; variant_inv 7 = scalar FMAs):
     // 4096^2 db4 74 us either way (the kernel sits on its memory floor), db6 116 -> 98 us, 2048^2 db4 27.1 -> 25.1 us per level.
     const int tiles2 = (a.n1 + fused2_tile_width(inverse, Lp, ew2) - 1) / fused2_tile_width(inverse, Lp, ew2);
-    const bool deep = inverse && (sizeof(T) == 4 || Lp <= 8) && ew2 == 1 && dil == 1 && vec4 && p->variant_inv != 1 && n2 >= 64 &&
+    const bool deep = inverse && Lp <= 12 && (sizeof(T) == 4 || Lp <= 8) && ew2 == 1 && dil == 1 && vec4 && p->variant_inv != 1 && n2 >= 64 &&
                       ((long long)tiles2 * ((n2 + 69) / 70) <= 1280 || p->variant_inv >= 2);
     const int pdepth = (p->variant_inv == 2 || p->variant_inv == 6) ? 2 : 4;
     const int waves = (deep && p->variant_inv != 2 && p->variant_inv != 4) ? 1024 : 2048;

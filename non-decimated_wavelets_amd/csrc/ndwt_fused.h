@@ -46,7 +46,9 @@ int fused2_tile_width(bool inverse, int Lp, int ew);
 int launch_fwd2_f32(const Fused2Args<float>& a, int Lp, bool vec4, int ew, const void* taps_dev, hipStream_t s);
 int launch_inv2_f32(const Fused2Args<float>& a, int Lp, bool vec4, int ew, const void* taps_dev, hipStream_t s);
 int launch_inv2p_f32(const Fused2Args<float>& a, int Lp, int depth, const void* taps_dev, hipStream_t s, int packed = 0);
-int launch_inv2p_f64(const Fused2Args<double>& a, int Lp, const void* taps_dev, hipStream_t s);   // up to 8 taps   // Inv2P: 2 or 4 rows in flight per wave
+int launch_inv2p_f64(const Fused2Args<double>& a, int Lp, const void* taps_dev, hipStream_t s);   // up to 8 taps
+int launch_fwd2_f32_14to20(const Fused2Args<float>& a, int Lp, bool vec4, const void* taps_dev, hipStream_t s);   // float real, db7 .. db10
+int launch_inv2_f32_14to20(const Fused2Args<float>& a, int Lp, bool vec4, const void* taps_dev, hipStream_t s);   // Inv2P: 2 or 4 rows in flight per wave
 int launch_fwd2_f64(const Fused2Args<double>& a, int Lp, bool vec4, int ew, const void* taps_dev, hipStream_t s);
 int launch_inv2_f64(const Fused2Args<double>& a, int Lp, bool vec4, int ew, const void* taps_dev, hipStream_t s);
 

@@ -1064,6 +1064,25 @@ def test_dec_rec_and_denoise_are_graph_capturable(d, sizes, wn, precision):
     assert torch.equal(y, yg) and torch.equal(r, rg) and torch.equal(den, dg)
 
 
+@pytest.mark.parametrize("sizes,wn,path", [([260, 96], "db7", "fused2d"), ([512, 70], "db8", "fused2d"), ([250, 65], "db9", "fused2d"),
+                                           ([264, 40], "db10", "fused2d"), ([236, 33], ["db10", "db7"], "fused2d"), ([128, 48], ["db2", "db9"], "fused2d")])
+def test_long_filters_2d_float(sizes, wn, path):
+    """db7 .. db10 on real float images: the register-only fused 2-D kernels on the 256-register budget (no spills), against the oracle"""
+    rng = np.random.default_rng(12)
+    wl = [wn] * 2 if isinstance(wn, str) else wn
+    x = rng.standard_normal(sizes)
+    w = ndwt.nd_dwt_2D(wn, sizes, "pres_l2_norm", 1, "precision", "single")
+    xg = _colmajor_gpu(x, "single")
+    y = w.dec(xg, 2)
+    assert list(w._plans.values())[0].describe() == path
+    assert _relerr(y.cpu().numpy(), orc.spatial_dec(x, wl, 2, 1)) <= TOL["single"]
+    c = rng.standard_normal(sizes + [7])
+    got = w.rec(_colmajor_gpu(c, "single")).cpu().numpy()
+    want = orc.spatial_rec(c, wl, 1)
+    assert np.abs(got - want).max() <= TOL["single"] * max(np.abs(want).max(), np.abs(c).max())
+    assert _relerr(w.rec(y).cpu().numpy(), x) < 1e-5
+
+
 @pytest.mark.parametrize("sizes,wn,precision", [([260, 96], "db4", "double"), ([512, 70], ["db2", "db3"], "double"), ([248, 64], "db1", "double"),
                                                 ([264, 130], "db6", "single"), ([256, 64], ["db2", "db2"], "single")])
 def test_2d_synthesis_with_rows_in_flight(sizes, wn, precision):
