@@ -341,8 +341,8 @@ static bool fused2_dilated_eligible(const ndwt_plan* p, long long stride, int* L
 static bool fused2_eligible(const ndwt_plan* p, long long stride, int* Lp_out) {
     if (p->path != NDWT_PATH_AUTO || stride != 1 || p->ndim != 2) return false;
     int Lp = p->filt[0].len > p->filt[1].len ? p->filt[0].len : p->filt[1].len;
-    if (Lp > (p->dtype == NDWT_F32 && p->complexity == NDWT_REAL ? 20 : 12)) return false;   // float real: db7 .. db10 on the 256-register budget
-    if (p->complexity != NDWT_REAL && Lp > 8) return false;
+    // float real: up to db10, complex64 and double real: up to db8 (256-register budget), complex128: up to db4
+    if (Lp > (p->dtype == NDWT_F32 ? (p->complexity == NDWT_REAL ? 20 : 16) : (p->complexity == NDWT_REAL ? 16 : 8))) return false;
     if (p->dims[0] >= (1LL << 30) || p->dims[1] >= (1LL << 30)) return false;
     *Lp_out = Lp;
     return true;
@@ -548,10 +548,12 @@ int fused2_tile_width(bool inverse, int Lp, int ew) {
 
 template <typename T> static int launch2(bool inverse, const Fused2Args<T>& a, int Lp, bool vec4, int ew, const void* td, hipStream_t s);
 template <> int launch2<float>(bool inverse, const Fused2Args<float>& a, int Lp, bool vec4, int ew, const void* td, hipStream_t s) {
+    if (ew == 2 && Lp > 8) return inverse ? launch_inv2_c64_10to16(a, Lp, vec4, td, s) : launch_fwd2_c64_10to16(a, Lp, vec4, td, s);
     if (Lp > 12) return ew != 1 ? -1 : (inverse ? launch_inv2_f32_14to20(a, Lp, vec4, td, s) : launch_fwd2_f32_14to20(a, Lp, vec4, td, s));
     return inverse ? launch_inv2_f32(a, Lp, vec4, ew, td, s) : launch_fwd2_f32(a, Lp, vec4, ew, td, s);
 }
 template <> int launch2<double>(bool inverse, const Fused2Args<double>& a, int Lp, bool vec4, int ew, const void* td, hipStream_t s) {
+    if (Lp > 12) return ew != 1 ? -1 : launch_long2_f64(inverse, a, Lp, vec4, td, s);
     return inverse ? launch_inv2_f64(a, Lp, vec4, ew, td, s) : launch_fwd2_f64(a, Lp, vec4, ew, td, s);
 }
 

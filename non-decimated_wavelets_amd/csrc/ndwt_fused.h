@@ -48,7 +48,10 @@ int launch_inv2_f32(const Fused2Args<float>& a, int Lp, bool vec4, int ew, const
 int launch_inv2p_f32(const Fused2Args<float>& a, int Lp, int depth, const void* taps_dev, hipStream_t s, int packed = 0);
 int launch_inv2p_f64(const Fused2Args<double>& a, int Lp, const void* taps_dev, hipStream_t s);   // up to 8 taps
 int launch_fwd2_f32_14to20(const Fused2Args<float>& a, int Lp, bool vec4, const void* taps_dev, hipStream_t s);   // float real, db7 .. db10
-int launch_inv2_f32_14to20(const Fused2Args<float>& a, int Lp, bool vec4, const void* taps_dev, hipStream_t s);   // Inv2P: 2 or 4 rows in flight per wave
+int launch_inv2_f32_14to20(const Fused2Args<float>& a, int Lp, bool vec4, const void* taps_dev, hipStream_t s);
+int launch_fwd2_c64_10to16(const Fused2Args<float>& a, int Lp, bool vec4, const void* taps_dev, hipStream_t s);    // interleaved complex64, db5 .. db8
+int launch_inv2_c64_10to16(const Fused2Args<float>& a, int Lp, bool vec4, const void* taps_dev, hipStream_t s);
+int launch_long2_f64(bool inverse, const Fused2Args<double>& a, int Lp, bool vec4, const void* taps_dev, hipStream_t s);   // double real, db7 / db8   // Inv2P: 2 or 4 rows in flight per wave
 int launch_fwd2_f64(const Fused2Args<double>& a, int Lp, bool vec4, int ew, const void* taps_dev, hipStream_t s);
 int launch_inv2_f64(const Fused2Args<double>& a, int Lp, bool vec4, int ew, const void* taps_dev, hipStream_t s);
 

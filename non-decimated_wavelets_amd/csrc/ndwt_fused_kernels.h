@@ -52,9 +52,12 @@ template <class K> int launch_fused2(const typename K::Args& a, const void* taps
                 return vec4 ? launch_fused2<KIND<T, LL, true, 4, 4>>(a, taps_dev, s) : launch_fused2<KIND<T, LL, false, 4, 4>>(a, taps_dev, s); \
         }                                                                                    \
         if (ew == 4) return -1;                                                              \
-        if (ew == 2)                                                                         \
-            return vec4 ? launch_fused2<KIND<T, LL, true, (sizeof(T) == 8 ? 2 : 4), 2>>(a, taps_dev, s)   \
-                        : launch_fused2<KIND<T, LL, false, (sizeof(T) == 8 ? 2 : 4), 2>>(a, taps_dev, s); \
+        if constexpr (LL <= 8) {   /* interleaved complex: up to 8 taps here (complex64 10 .. 16: ndwt_fused2_f32_{fwdc,invc}.hip) */ \
+            if (ew == 2)                                                                     \
+                return vec4 ? launch_fused2<KIND<T, LL, true, (sizeof(T) == 8 ? 2 : 4), 2>>(a, taps_dev, s)   \
+                            : launch_fused2<KIND<T, LL, false, (sizeof(T) == 8 ? 2 : 4), 2>>(a, taps_dev, s); \
+        }                                                                                    \
+        if (ew == 2) return -1;                                                              \
         return vec4 ? launch_fused2<KIND<T, LL, true, (sizeof(T) == 8 ? 2 : 4)>>(a, taps_dev, s) : launch_fused2<KIND<T, LL, false, (sizeof(T) == 8 ? 2 : 4)>>(a, taps_dev, s);
 // (the tap lengths are split over two translation units per kernel family: one unit with all of them is the long pole of the build)
 #define NDWT_FUSED2_SWITCH_SHORT(KIND, T) \

@@ -1083,6 +1083,29 @@ def test_long_filters_2d_float(sizes, wn, path):
     assert _relerr(w.rec(y).cpu().numpy(), x) < 1e-5
 
 
+@pytest.mark.parametrize("sizes,wn,precision,cplx,path", [
+    ([130, 48], "db5", "single", True, "fused2d"), ([128, 40], "db6", "single", True, "fused2d"), ([131, 36], "db7", "single", True, "fused2d"),
+    ([132, 33], ["db8", "db5"], "single", True, "fused2d"), ([128, 40], "db9", "single", True, "axis"),
+    ([260, 40], "db7", "double", False, "fused2d"), ([250, 33], ["db8", "db2"], "double", False, "fused2d"), ([128, 40], "db9", "double", False, "axis"),
+    ([128, 40], "db5", "double", True, "axis"),
+])
+def test_long_filters_2d_complex64_and_double(sizes, wn, precision, cplx, path):
+    """2-D fused kernels beyond db6 / db4: interleaved complex64 with 10 .. 16 taps and real double with 14 / 16 taps (256-register budget)"""
+    rng = np.random.default_rng(14)
+    wl = [wn] * 2 if isinstance(wn, str) else wn
+    x = rng.standard_normal(sizes) + (1j * rng.standard_normal(sizes) if cplx else 0)
+    w = ndwt.nd_dwt_2D(wn, sizes, "pres_l2_norm", 1, "precision", precision)
+    xg = _colmajor_gpu(x, precision)
+    y = w.dec(xg, 2)
+    assert list(w._plans.values())[0].describe() == path
+    assert _relerr(y.cpu().numpy(), orc.spatial_dec(x, wl, 2, 1)) <= TOL[precision]
+    c = rng.standard_normal(sizes + [7]) + (1j * rng.standard_normal(sizes + [7]) if cplx else 0)
+    got = w.rec(_colmajor_gpu(c, precision)).cpu().numpy()
+    want = orc.spatial_rec(c, wl, 1)
+    assert np.abs(got - want).max() <= TOL[precision] * max(np.abs(want).max(), np.abs(c).max())
+    assert _relerr(w.rec(y).cpu().numpy(), x) < (1e-13 if precision == "double" else 1e-5)
+
+
 @pytest.mark.parametrize("sizes,wn,precision", [([260, 96], "db4", "double"), ([512, 70], ["db2", "db3"], "double"), ([248, 64], "db1", "double"),
                                                 ([264, 130], "db6", "single"), ([256, 64], ["db2", "db2"], "single")])
 def test_2d_synthesis_with_rows_in_flight(sizes, wn, precision):
