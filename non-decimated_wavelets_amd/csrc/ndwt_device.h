@@ -416,9 +416,13 @@ struct PkF32 {
 // modifiers of the packed FMA (PkF32) -- 4 L SGPRs instead of 12 L, so nothing is re-loaded from constant memory inside the loop (the
 // plain form issues 27 scalar loads per plane with 8 taps, 40 with 12).  Needs even zero padding of every axis' taps (the host checks).
 template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, int WPE_ = 2, int EW_ = 1, bool LOWONLY_ = false, bool TPRE_ = false,
-          bool PIN_ = false> struct Fwd3 {
+          bool PIN_ = false, int WLDS_ = 0> struct Fwd3 {
     static constexpr int L = L_, TX = TX_, TY = TY_, NT = NT_, RY = RY_, EW = EW_;
     static constexpr bool LOWONLY = LOWONLY_, TPRE = TPRE_, PIN = PIN_;
+    // WLDS_ > 0: that many of the L slots of a thread's z window live in LDS instead of registers (each is written and read by its own
+    // thread only: no barrier) -- what keeps 16 .. 20 taps inside the 128 registers of the 1024-thread tile without spills
+    static constexpr int WLDS = WLDS_;
+    static_assert(WLDS_ >= 0 && WLDS_ < L_, "at least one window slot stays in registers");
     static_assert(!PIN_ || sizeof(T) == 4, "pinned / derived taps: float only (v_pk_fma_f32)");
     static_assert(!TPRE_ || VEC4_, "the folded t axis exists for rows of whole groups of 4 scalars");
     static constexpr bool VEC4 = VEC4_;
@@ -450,9 +454,10 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
     struct Shared {
         chunk zs[NR][WC];        // (lo3, hi3) of the raw tile
         chunk ys[TY][2][WC];     // [row][y-bit][x] of (z-bit 0, z-bit 1); y-bit planes of a row are a multiple of 256 B apart
+        v4 zw[WLDS ? WLDS : 1][WLDS ? NCOL * NT : 1];   // [slot][column of the thread]: the window slots that do not live in registers
     };
     struct State {
-        v4 win[NCOL][L];     // raw samples of the last L planes, rotating
+        v4 win[NCOL][L - WLDS];   // raw samples of the last L planes, rotating (slots WLDS .. L-1; slots 0 .. WLDS-1: Shared::zw)
         v4 nxt[NCOL];        // prefetched plane
         v4 tfr[TPRE ? L : 1][NCOL];   // TPRE: the prefetched plane of the L frames under the t filter
         int off[NCOL][NE];
@@ -462,6 +467,14 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
         v2 ax[PIN ? L / 2 : 1], ay[PIN ? L / 2 : 1];     // (lo[2m], lo[2m+1]) of the x and y axes
         v2 az[PIN ? L : 1];                              // (lo_z[j], hi_z[j])
     };
+    template <int SLOT> static NDWT_DEV v4 win_get(const State& st, const Shared& sh, int k, int tid) {
+        if constexpr (SLOT < WLDS) return sh.zw[SLOT][k * NT + tid];
+        else return st.win[k][SLOT - WLDS];
+    }
+    template <int SLOT> static NDWT_DEV void win_put(State& st, Shared& sh, int k, int tid, v4 v) {
+        if constexpr (SLOT < WLDS) sh.zw[SLOT][k * NT + tid] = v;
+        else st.win[k][SLOT - WLDS] = v;
+    }
     static NDWT_DEV void load_regt(RegT& rt, const Taps& tp) {
         if constexpr (PIN) {
             NDWT_SFOR(m, L / 2)
@@ -535,13 +548,13 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
     // rotation R: the newest plane lands in slot (R+L-1)%L; tap j reads slot (R+j)%L
     template <int R> static NDWT_DEV void zstage(State& st, Shared& sh, const Taps& tp, const RegT& rt, int tid) {
         NDWT_SFOR(k, NCOL)
-            st.win[k][(R + L - 1) % L] = st.nxt[k];
+            win_put<(R + L - 1) % L>(st, sh, k, tid, st.nxt[k]);
             int c = tid + k * NT;
             if (c < NCOLS) {
                 v2 acc[4];
                 acc[0] = acc[1] = acc[2] = acc[3] = (v2)(T(0));
                 NDWT_SFOR(j, L)
-                    v4 w = st.win[k][(R + j) % L];
+                    v4 w = (j == L - 1) ? st.nxt[k] : win_get<(R + j) % L>(st, sh, k, tid);   // (the newest plane is still in registers)
                     if constexpr (PIN) {                  // (lo, hi) += w[e] * (lo_z[j], hi_z[j]): the sample broadcast from a half of its register pair
                         const v2 w01 = {w[0], w[1]}, w23 = {w[2], w[3]};
                         PkF32::fma_bt<0, false, false, false>(acc[0], w01, rt.az[j]);
@@ -564,11 +577,11 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
             else zdispatch<R + 1>(r, st, sh, tp, rt, tid);
         }
     }
-    static NDWT_DEV void prologue(State& st, const Args& a, const T* inb, int zbeg) {
+    static NDWT_DEV void prologue(State& st, Shared& sh, const Args& a, const T* inb, int zbeg, int tid) {
         NDWT_SFOR(j, L - 1)
             load_plane(st, a, inb, zbeg - LH + j);
             NDWT_SFOR(k, NCOL)
-                st.win[k][j] = st.nxt[k];
+                win_put<j>(st, sh, k, tid, st.nxt[k]);
             NDWT_SEND
         NDWT_SEND
     }
@@ -740,11 +753,11 @@ template <typename T, int L_, int TX_, int TY_, int NT_, int RY_, bool VEC4_, in
                     load_frames(st, a, tf, tc.zbeg - LH + j);
                     tcombine(st, a);
                     NDWT_SFOR(k, NCOL)
-                        st.win[k][j] = st.nxt[k];
+                        win_put<j>(st, sh, k, tid, st.nxt[k]);
                     NDWT_SEND
                 NDWT_SEND
             } else {
-                prologue(st, a, inb, tc.zbeg);
+                prologue(st, sh, a, inb, tc.zbeg, tid);
             }
             fetch(st, tc.zbeg + RH);
         });

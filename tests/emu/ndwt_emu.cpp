@@ -614,6 +614,10 @@ extern "C" int ndwt_emu_pin3_f32(int Lp, const float* x, float* out, int n1, int
         case 10: return run_pin3<10>(a, alo, ahi);
         case 12: return run_pin3<12>(a, alo, ahi);
         case 14: return run_pin3<14>(a, alo, ahi);
+        case 16: {   // 16 taps: plain taps, 2 of the 16 z-window slots in LDS (Fwd3 WLDS)
+            typedef ndwt::Fused3Tile<float, false, 6> TL;
+            return run<ndwt::Fwd3<float, 16, TL::TX, TL::TY, TL::NT, TL::RY, true, 2, 1, false, false, false, 2>, float>(a, alo, ahi);
+        }
         default: return -1;
     }
 }
