@@ -11,6 +11,28 @@ int launch_long3_f32(bool inverse, const Fused3Args<float>& a, const FusedTapsD&
             typedef Fused3Tile<float, false, 6> TL;
             return launch_fused3<Fwd3<float, 16, TL::TX, TL::TY, TL::NT, TL::RY, true, TL::WPE, 1, false, false, false, 2>>(a, t, taps_dev, s);
         }
+        // 20 taps on rows of whole groups of 4: 4 of the 20 window slots of each of a thread's two columns in LDS -- the 512-thread tile
+        // without its 18 spilled registers: 512^3 db10 analysis 2.79 -> 1.95 ms per launch, bit-identical; 18 taps (no spills as they are) gain nothing from it (variant_fwd 3: the spilling form)
+        if (t.Lp == 20 && vec4 && variant != 3) {
+            typedef Fused3Tile<float, false, 1> TL;
+            return launch_fused3<Fwd3<float, 20, TL::TX, TL::TY, TL::NT, TL::RY, true, TL::WPE, 1, false, false, false, 4>>(a, t, taps_dev, s);
+        }
+        // 16 taps on rows of whole groups of 4: two of the 16 slots of the z window in LDS (Fwd3 WLDS) keep the tall tile free of spills --
+        // 512^3 db8 analysis 1.53 -> 1.16 ms per launch, bit-identical (pinned taps on top: 1.20, not used; variant_fwd 3: the spilling form)
+        if (t.Lp == 16 && vec4 && variant != 1 && variant != 3) {
+            typedef Fused3Tile<float, false, 6> TL;
+            return launch_fused3<Fwd3<float, 16, TL::TX, TL::TY, TL::NT, TL::RY, true, TL::WPE, 1, false, false, false, 2>>(a, t, taps_dev, s);
+        }
+        // 20 taps on rows of whole groups of 4: 4 of the 20 window slots of each of a thread's two columns in LDS -- the 512-thread tile
+        // without its 18 spilled registers: 512^3 db10 analysis 2.79 -> 1.95 ms per launch, bit-identical; 18 taps (no spills as they are) gain nothing from it (variant_fwd 3: the spilling form)
+        if (t.Lp == 20 && vec4 && variant != 3) {
+            typedef Fused3Tile<float, false, 1> TL;
+            return launch_fused3<Fwd3<float, 20, TL::TX, TL::TY, TL::NT, TL::RY, true, TL::WPE, 1, false, false, false, 4>>(a, t, taps_dev, s);
+        }
+        if (t.Lp == 18 && vec4 && variant == 10) {   // A/B
+            typedef Fused3Tile<float, false, 1> TL;
+            return launch_fused3<Fwd3<float, 18, TL::TX, TL::TY, TL::NT, TL::RY, true, TL::WPE, 1, false, false, false, 4>>(a, t, taps_dev, s);
+        }
         if (variant != 1) {       // default: tall 64x32 tile, 1024 threads (db7 analysis 1.45 -> 1.15 ms per launch; 16 taps on ragged rows spill 8 registers)
             switch (t.Lp) {
                 NDWT_FUSED_CASE(Fwd3, false, float, 14, 6)   // (y items of 2 rows: ndwt_fused_tile.h)

@@ -618,6 +618,11 @@ extern "C" int ndwt_emu_pin3_f32(int Lp, const float* x, float* out, int n1, int
             typedef ndwt::Fused3Tile<float, false, 6> TL;
             return run<ndwt::Fwd3<float, 16, TL::TX, TL::TY, TL::NT, TL::RY, true, 2, 1, false, false, false, 2>, float>(a, alo, ahi);
         }
+        case 20: {   // 20 taps: the 512-thread 64x16 tile, two columns per thread, 4 of the 20 window slots of each in LDS
+            typedef ndwt::Fused3Tile<float, false, 1> TL;
+            ndwt::fused3_geometry(a, TL::TX, TL::TY, Lp, 4, zchunk);
+            return run<ndwt::Fwd3<float, 20, TL::TX, TL::TY, TL::NT, TL::RY, true, 2, 1, false, false, false, 4>, float>(a, alo, ahi);
+        }
         default: return -1;
     }
 }

@@ -156,6 +156,7 @@ def test_headline_kernels_do_not_spill():
         "Fwd3IfLi12ELi64ELi32ELi1024ELi2ELb1",          # cfg4 analysis (plain form and the pinned-tap form, ..ELb0ELb0ELb1)
         "Fwd3IfLi10ELi64ELi32ELi1024ELi2ELb1", "Fwd3IfLi14ELi64ELi32ELi1024ELi2ELb1",
         "Fwd3IfLi16ELi64ELi32ELi1024ELi2ELb1ELi4ELi1ELb0ELb0ELb0ELi2",   # 16 taps: two window slots in LDS
+        "Fwd3IfLi20ELi64ELi16ELi512ELi4ELb1ELi2ELi1ELb0ELb0ELb0ELi4",    # 20 taps: four
         "Fwd2SIfLi8ELb1", "Inv2SIfLi8ELb1", "Inv2PIfLi8ELi4E",   # cfg2 (synthesis: Inv2P, 4 rows in flight)
         "Den3IfLi2E", "Den3IfLi4E", "Den3IfLi6E", "Den3IfLi8E",
         "Inv3YIfLi18E", "Inv3YIfLi20E",

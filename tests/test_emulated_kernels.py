@@ -518,9 +518,11 @@ def test_emulated_approximation_only_analysis(emu, sizes, wname, vec4, zchunk):
 @pytest.mark.slow
 @pytest.mark.parametrize("sizes,wnames,zchunk", [((68, 36, 9), ("db6",) * 3, 0), ((72, 40, 16), ("db5",) * 3, 6), ((64, 32, 5), ("db7",) * 3, 0),
                                                  ((128, 33, 7), ("db6", "db2", "db4"), 3), ((16, 12, 14), ("db6",) * 3, 0),
-                                                 ((68, 36, 9), ("db8",) * 3, 0), ((72, 40, 20), ("db8", "db4", "db8"), 7)])
+                                                 ((68, 36, 9), ("db8",) * 3, 0), ((72, 40, 20), ("db8", "db4", "db8"), 7),
+                                                 ((68, 20, 22), ("db10",) * 3, 0), ((64, 33, 24), ("db10", "db6", "db8"), 9)])
 def test_emulated_analysis_with_pinned_taps(emu, sizes, wnames, zchunk):
-    """16 taps: Fwd3<.., WLDS = 2> -- two slots of every thread's z window in LDS, the other 14 in registers, plain taps.
+    """16 / 20 taps: Fwd3<.., WLDS = 2 / 4> -- that many slots of every thread's z window in LDS, the others in registers, plain taps
+    (20 taps: the 512-thread 64 x 16 tile with two columns per thread).
     Fwd3<.., PIN> (float real, 10 / 12 / 14 taps on vec4 data): tap pairs pinned in scalar registers, the high-pass taps taken from
     the low-pass pairs through the operand modifiers of the packed FMA (mirror + alternating signs, which survives an EVEN zero padding
     of a shorter axis' taps) -- all 8 bands against the oracle"""
