@@ -17,6 +17,11 @@ int launch_long3_f32(bool inverse, const Fused3Args<float>& a, const FusedTapsD&
             typedef Fused3Tile<float, false, 1> TL;
             return launch_fused3<Fwd3<float, 20, TL::TX, TL::TY, TL::NT, TL::RY, true, TL::WPE, 1, false, false, false, 4>>(a, t, taps_dev, s);
         }
+        if (!vec4 && variant != 3 && (t.Lp == 18 || t.Lp == 20)) {   // ragged rows: 2 / 6 slots in LDS, no spills (8 / 33 without)
+            typedef Fused3Tile<float, false, 1> TL;
+            if (t.Lp == 18) return launch_fused3<Fwd3<float, 18, TL::TX, TL::TY, TL::NT, TL::RY, false, TL::WPE, 1, false, false, false, 2>>(a, t, taps_dev, s);
+            return launch_fused3<Fwd3<float, 20, TL::TX, TL::TY, TL::NT, TL::RY, false, TL::WPE, 1, false, false, false, 6>>(a, t, taps_dev, s);
+        }
         // 16 taps on rows of whole groups of 4: two of the 16 slots of the z window in LDS (Fwd3 WLDS) keep the tall tile free of spills --
         // 512^3 db8 analysis 1.53 -> 1.16 ms per launch, bit-identical (pinned taps on top: 1.20, not used; variant_fwd 3: the spilling form)
         if (t.Lp == 16 && vec4 && variant != 1 && variant != 3) {

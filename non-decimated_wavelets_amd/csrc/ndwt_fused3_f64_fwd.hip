@@ -4,6 +4,10 @@ namespace ndwt {
 int launch_fwd3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4, int variant, int ew, const void* taps_dev, hipStream_t s) {
     if (ew != 1 && ew != 2) return -1;
     if (ew == 2) {
+        if (t.Lp == 12 && vec4) {   // complex128 db6: two of the 12 z-window slots in LDS (Fwd3 WLDS): 2 spilled registers instead of 16
+            typedef Fused3Tile<double, false, 5> TL;
+            return launch_fused3<Fwd3<double, 12, TL::TX, TL::TY, TL::NT, TL::RY, true, TL::WPE, 2, false, false, false, 2>>(a, t, taps_dev, s);
+        }
         switch (t.Lp) {
             NDWT_FUSED_CASE_C(Fwd3, false, double, 2, 0)
             NDWT_FUSED_CASE_C(Fwd3, false, double, 4, 0)
