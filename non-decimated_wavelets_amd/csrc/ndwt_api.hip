@@ -398,6 +398,14 @@ static bool inv3y_plan_ok(const ndwt_plan* p, int Lp) {
     return p->dims[0] * p->comp * p->dims[1] < (1LL << 30);
 }
 
+// the y and z axes carry the same synthesis taps (the same wavelet): the pair-packed kernel then keeps one set of tap pairs for both
+static bool uniform_yz(const ndwt_plan* p) {
+    if (p->ndim < 3 || p->filt[1].len != p->filt[2].len) return false;
+    for (int j = 0; j < p->filt[1].len; ++j)
+        if (p->filt[1].syn_lo[j] != p->filt[2].syn_lo[j]) return false;
+    return true;
+}
+
 // Nontemporal output stores: float data whose output rows are whole 128-byte lines (a nontemporal store of a partly covered line
 // is a read-modify-write in memory; plain stores of neighbouring tiles merge in L2).  Double never (ndwt_device.h: stream_store).
 template <typename T> static int nt_store_ok(long long rs, long long plane, long long bstride, T* const* out, int nout) {
@@ -510,7 +518,7 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     if constexpr (sizeof(T) == 4) {
         if (use_y) {
             rc = ew == 4 ? (vec4 ? launch_inv3y4_f32(a, Lp, variant == 5 ? 1 : 2, td, s) : -1)
-                 : ew == 2 ? launch_inv3yc_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s) : launch_inv3y_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s);
+                 : ew == 2 ? launch_inv3yc_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s) : launch_inv3y_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s, uniform_yz(p) && variant != 9);
             if (rc == -1) {                               // the geometry above is this kernel's: never fall through to another one with it
                 prof_end(p, s, rc);
                 return fail(NDWT_ERR_UNSUPPORTED, "pair-packed synthesis kernel not instantiated for tap length %d", Lp);

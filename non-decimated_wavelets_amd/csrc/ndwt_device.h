@@ -1359,7 +1359,10 @@ template <typename T, int L> struct Taps3Y {             // the first two member
 // registers of a 1024-thread workgroup without spills.
 // XH_ > 0: every haloed row carries that many more lanes on each side than the synthesis needs (Den3: the lanes whose coefficients
 // exist only as inputs of the neighbouring lanes' x analysis).
-template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 4, int DEPTH_ = 1, int EW_ = 1, int ZLDS_ = 0, int XH_ = 0> struct Inv3Y {
+// UNIYZ_: the y and z axes carry the same taps (the same wavelet, the usual case): the z stage reads the y tap pairs, which frees L SGPRs
+// (the kernel holds (L + 1) + L tap pairs, 8 band pointers and its loop scalars in ~100 SGPRs and spills the rest to VGPR lanes).
+template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 4, int DEPTH_ = 1, int EW_ = 1, int ZLDS_ = 0, int XH_ = 0,
+          bool UNIYZ_ = false> struct Inv3Y {
     static_assert(sizeof(T) == 4, "pair-packed synthesis: float only (v_pk_fma_f32)");
     static_assert(EW_ == 1 || EW_ == 2 || EW_ == 4, "real data, interleaved complex data / a level dilated by 2, a level dilated by 4");
     static constexpr int L = L_, TX = TX_, TY = TY_, NT = NT_, WPE = WPE_, EW = EW_;
@@ -1372,6 +1375,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
     static constexpr int LH = L / 2, RH = L / 2 - 1;
     static constexpr int GL = (LH * EW + 3) / 4, GR = (RH * EW + 3) / 4;
     static constexpr int XH = XH_;
+    static constexpr bool UNIYZ = UNIYZ_;
     static constexpr int NG = TX / 4 + GL + GR + 2 * XH; // lanes per haloed row
     static constexpr int NR = TY + L - 1;                // haloed rows: loaded, x-synthesised, kept in LDS
     static constexpr int RPW = 64 / NG;                  // rows per wave
@@ -1432,8 +1436,12 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
         }
         NDWT_SFOR(m, L / 2)
             rt.yl[m] = pinned(v2{tp.lo[1][2 * m], tp.lo[1][2 * m + 1]});
-            rt.zl[m] = pinned(v2{tp.lo[2][2 * m], tp.lo[2][2 * m + 1]});
+            if constexpr (!UNIYZ) rt.zl[m] = pinned(v2{tp.lo[2][2 * m], tp.lo[2][2 * m + 1]});
         NDWT_SEND
+    }
+    static NDWT_DEV const v2 (&ztaps(const RegTaps& rt))[L / 2] {
+        if constexpr (UNIYZ) return rt.yl;
+        else return rt.zl;
     }
 
     // Global memory through a WAVE-UNIFORM base (kernel arguments and tile coordinates only) plus a 32-bit per-lane byte
@@ -1680,14 +1688,14 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
                     constexpr int slot = ((R - 1 - j) % L + L) % L;
                     if constexpr (slot < L - ZLDS) {
                         if constexpr (j == 0) st.zacc[k][slot] = (v2)(T(0));
-                        tap_fma<j, false>(st.zacc[k][slot], P0, tp.zl);
-                        tap_fma<j, true>(st.zacc[k][slot], P1, tp.zl);
+                        tap_fma<j, false>(st.zacc[k][slot], P0, ztaps(tp));
+                        tap_fma<j, true>(st.zacc[k][slot], P1, ztaps(tp));
                         if constexpr (j == L - 1) o = st.zacc[k][slot];
                     } else {
                         v2 acc = (v2)(T(0));
                         if constexpr (j != 0) acc = sh.zl[slot - (L - ZLDS)][it];
-                        tap_fma<j, false>(acc, P0, tp.zl);
-                        tap_fma<j, true>(acc, P1, tp.zl);
+                        tap_fma<j, false>(acc, P0, ztaps(tp));
+                        tap_fma<j, true>(acc, P1, ztaps(tp));
                         if constexpr (j == L - 1) o = acc;
                         else sh.zl[slot - (L - ZLDS)][it] = acc;
                     }
