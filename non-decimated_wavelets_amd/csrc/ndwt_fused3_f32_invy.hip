@@ -26,13 +26,12 @@ template <int LL, bool V, int DEPTH, bool UNI = false> static int go(const Fused
         return vec4 ? go<LL, true, 1>(a, taps_dev, s) : go<LL, false, 1>(a, taps_dev, s);
 
 int launch_inv3y_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, const void* taps_dev, hipStream_t s, int uniform_yz) {
-    // the same taps on the y and z axes, rows of whole groups of 4, the default depth: the instance whose z stage reads the y tap pairs
-    // (L fewer SGPRs held: 512^3 synthesis db4 -1.3 %, db6 -1.2 %, db10 -2.4 % per launch; results identical)
+    // the same taps on the y and z axes, rows of whole groups of 4, the default depth, 12 .. 20 taps: the instance whose z stage reads the y
+    // tap pairs (L fewer SGPRs held: 512^3 synthesis db6 -1.8 %, db10 -2.4 % per launch, identical results).  8 taps: -0.6 % on cfg3 and
+    // +1.2 % on cfg5's batched volumes in interleaved A/B runs -- within noise of each other, so the 8- and 10-tap kernels stay as they were.
     if (uniform_yz && vec4) {
         switch (Lp) {
-            case 8: if (depth == 2) return go<8, true, 2, true>(a, taps_dev, s); break;
 #ifndef NDWT_INVY_DB4_ONLY
-            case 10: if (depth == 2) return go<10, true, 2, true>(a, taps_dev, s); break;
             case 12: if (depth == 2) return go<12, true, 2, true>(a, taps_dev, s); break;
             case 14: return go<14, true, 1, true>(a, taps_dev, s);
             case 16: return go<16, true, 1, true>(a, taps_dev, s);

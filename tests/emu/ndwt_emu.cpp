@@ -435,7 +435,6 @@ int emu_y_prod(int depth, int Lp, int vec4, ndwt::Fused3Args<float>& a, const do
     // the same taps on y and z, two register sets, rows of whole groups of 4: the instance whose z stage reads the y tap pairs (UNIYZ), as the library
     bool uni = depth == 2 && vec4;
     for (int j = 0; j < Lp; ++j) uni = uni && lo[1 * ndwt::kMaxTaps + j] == lo[2 * ndwt::kMaxTaps + j];
-    if (uni && Lp == 8) return runY<ndwt::Inv3Y<float, 8, ndwt::kInv3YTX, ndwt::kInv3YTY, 1024, true, 2, 2, 1, ndwt::inv3y_zlds(8, 2), 0, true>, float>(a, lo, hi);
     if (uni && Lp == 12) return runY<ndwt::Inv3Y<float, 12, ndwt::kInv3YTX, ndwt::kInv3YTY, 1024, true, 2, 2, 1, ndwt::inv3y_zlds(12, 2), 0, true>, float>(a, lo, hi);
     return depth == 1 ? dispatchY<float, ndwt::kInv3YTX, ndwt::kInv3YTY, 1024, false, 1>(Lp, vec4, a, lo, hi)
                       : dispatchY<float, ndwt::kInv3YTX, ndwt::kInv3YTY, 1024, false, 2>(Lp, vec4, a, lo, hi);
