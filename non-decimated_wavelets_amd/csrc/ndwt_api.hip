@@ -488,7 +488,8 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     if constexpr (sizeof(T) == 4) {
         // (plane offsets stay below 2^32 bytes: checked there).  A level dilated by 2 on real data is the interleaved-pair form of the
         // kernel (the two x sub-lattices are its (re, im) halves): 512^3 db4 synthesis at tap stride 2 1.52 -> see DESIGN 4.6
-        use_y = inverse && (dil == 1 || ((dil == 2 || dil == 4) && p->comp == 1 && p->variant_inv != 2)) && inv3y_plan_ok(p, Lp);
+        use_y = inverse && (dil == 1 || ((dil == 2 || (dil == 4 && vec4)) && p->comp == 1 && p->variant_inv != 2)) && inv3y_plan_ok(p, Lp);
+        // (the whole-lane-shift form of tap stride 4 exists for 16-byte-aligned data only: anything else keeps Inv3S<.., EW = 4>)
         if (use_y) { TX = ndwt::inv3y_tx(Lp, ew); TY = ndwt::inv3y_ty(Lp, ew); }
     }
     const int zc_force = p->zchunk_dir[inverse ? 1 : 0] > 0 ? p->zchunk_dir[inverse ? 1 : 0] : p->force_zchunk;

@@ -326,6 +326,27 @@ def test_atrous_levels_on_sublattices(sizes, wn, precision):
     assert _relerr(wg.dec(xg, 3).cpu().numpy(), w.dec(xg, 3).cpu().numpy()) <= tol
 
 
+def test_atrous_level3_rec_on_buffers_that_are_not_16_byte_aligned():
+    """float a-trous synthesis at tap stride 4 has a whole-lane-shift kernel for 16-byte-aligned data only; a coefficient or output
+    pointer off by one element must fall back to Inv3S<.., EW = 4> and give the same numbers (ndwt_rec states no alignment contract)"""
+    rng = np.random.default_rng(43)
+    sizes, wn, level = [24, 20, 16], ["db4", "db2", "db3"], 3
+    c = rng.standard_normal(sizes + [ndwt.num_bands(3, level)])
+    want = orc.spatial_rec(c, wn, 1, "atrous")
+    ck = torch.from_numpy(np.ascontiguousarray(np.transpose(c))).float()            # kernel order (bands, n3, n2, n1)
+    plan = ndwt.Plan(sizes, wn, torch.float32, False, True, "atrous", max_level=level)
+    vol = int(np.prod(sizes))
+    for off_in, off_out in ((0, 0), (1, 0), (0, 1), (1, 1)):
+        ybuf = torch.zeros(ck.numel() + 4, dtype=torch.float32, device="cuda")
+        ybuf[off_in:off_in + ck.numel()] = ck.reshape(-1).cuda()
+        xbuf = torch.zeros(vol + 4, dtype=torch.float32, device="cuda")
+        plan.rec(ybuf.data_ptr() + 4 * off_in, xbuf.data_ptr() + 4 * off_out, level, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = np.transpose(xbuf[off_out:off_out + vol].reshape(sizes[::-1]).cpu().numpy())
+        assert _relerr(got, want) <= 4 * TOL["single"], (off_in, off_out)
+        assert float(xbuf[:off_out].abs().sum()) == 0 and float(xbuf[off_out + vol:].abs().sum()) == 0   # nothing outside the output
+
+
 @pytest.mark.parametrize("sizes,wn,precision", [
     ([72, 40], ["db4", "db2"], "single"),        # both axes divide by 4: levels 2 and 3 fused on sub-lattices
     ([264, 36], ["db3", "db4"], "single"),       # two wave tiles along x
@@ -467,7 +488,7 @@ def test_long_filters_float(sizes, wn, path):
     ([64, 40, 36], ["db8", "db3", "db7"], "fused3d"),                  # mixed wavelets padded to 16 taps (odd and even padding)
     ([64, 40, 36], "db9", "axis"),                                     # 18 / 20 taps: per-axis path (the fused form spills 400+ registers)
 ])
-def test_long_filters_double(sizes, wn, path):
+def test_long_filters_double_14_16_taps(sizes, wn, path):
     """db7 / db8 on real double data (the reference mex path's precision, Test/nddwt3D_test.m:11 wavelets): fused, parity with the oracle"""
     rng = np.random.default_rng(7)
     x = rng.standard_normal(sizes)
@@ -539,7 +560,7 @@ def test_tall_analysis_tile_against_oracle(sizes, wn, cplx):
     ([68, 41, 30], "db6"),                                             # 64 x 8 tiles with 512 threads in both directions
     ([70, 37, 33], ["db6", "db5", "db3"]),                             # scalar accesses, mixed wavelets
 ])
-def test_long_filters_double(sizes, wn):
+def test_long_filters_double_10_12_taps(sizes, wn):
     """fp64 with 10 / 12 taps on the fused kernels (spill-free 64 x 8 tiles)"""
     rng = np.random.default_rng(7)
     x = rng.standard_normal(sizes)
