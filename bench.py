@@ -38,6 +38,8 @@ def parse_args():
     ap.add_argument("--wname", default="db4")
     ap.add_argument("--level", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-full", action="store_true", help="time the CPU baseline on the whole workload instead of the bounded sample "
+                    "(512^3 complex128: ~160 GiB of host memory and minutes of CPU time)")
     ap.add_argument("--generic", action="store_true", help="force the per-axis kernels (for comparison)")
     ap.add_argument("--band-pitch", default="packed", choices=["packed", "auto"],
                     help="layout of the coefficient buffer between dec and rec: packed = the reference's; auto = ndwt_band_pitch()")
@@ -95,7 +97,8 @@ def cpu_baseline(level, wname, sample_sizes, workers):
             s0 = (nb - 1) * (lev - 1)
             out[s0:s0 + nb] = sfft.ifftn(approx[None] * f_dec, axes=axes, norm="forward")   # pointByPoint + batched inverse
             approx = sfft.fftn(out[s0])
-        y = out.real
+        y = np.ascontiguousarray(out.real)
+        del out, approx
         # rec: nd_dwt_3D.m:220 + nddwt.c:242-292
         c_f = sfft.fftn(y, axes=axes)
         cur = None
@@ -168,6 +171,35 @@ def measure_config(api, torch, dev, d, sizes, wname, level, steps, warmup):
            "value": round(V / dt / 1e6, 1), "unit": "Mvoxels/s", "algorithmic_bytes_per_step": step_bytes,
            "whole_step_frac": round(step_bytes / dt / 1e9 / HBM_PEAK_GBS, 4), "kernels": kern, "roundtrip_rel_l2": rt}
     del plan, x, y, r
+    torch.cuda.empty_cache()
+    return out
+
+
+def one_rank_share(sh, torch, dev, wname, level, whole_ms, n_local=64, steps=100):
+    """One rank's share of an 8-GPU run of a 512^3 volume, measured on THIS GPU: the 512 x 512 x n_local slab through the sharded driver
+    at world size 1 (every exchange segment is a local copy, so this is the compute side only -- the projection `before communication`),
+    with the exchange overlapped (interior planes, then the ends: 2 launches per level and direction) and in one piece per level, plus
+    what tune() picks.  `x8_equivalent` = whole-volume ms / share ms: what 8 such ranks would give if the exchange were free."""
+    import time
+    x = torch.randn(n_local, 512, 512, device=dev, dtype=torch.float32)
+    out = {"slab": f"512x512x{n_local} fp32 {wname} {level} levels, world size 1 (local-copy exchange)", "steps": steps,
+           "whole_volume_ms": round(whole_ms, 4)}
+    for key, mode in (("one_piece", False), ("overlap", True)):
+        eng = sh.ShardedNdDwt([wname] * 3, [512, 512, n_local], pres_l2_norm=True, precision="single", device=dev, overlap=mode)
+        for _ in range(5):
+            r = eng.rec(eng.dec(x, level))
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = eng.rec(eng.dec(x, level))
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        out[key] = {"ms_per_dec_rec": round(ms, 4), "x8_equivalent": round(whole_ms / ms, 2),
+                    "roundtrip_rel_l2": float(torch.linalg.vector_norm((r - x).double()) / torch.linalg.vector_norm(x.double()))}
+        del eng
+    eng = sh.ShardedNdDwt([wname] * 3, [512, 512, n_local], pres_l2_norm=True, precision="single", device=dev)   # overlap="auto"
+    out["auto"] = eng.tune(x, level, steps=10)
+    del eng, x
     torch.cuda.empty_cache()
     return out
 
@@ -275,9 +307,12 @@ def main():
             plan.rec(lay["y"].data_ptr(), r.data_ptr(), level, stream, band_pitch=lay["pitch"])
     else:
         sh = importlib.import_module("non-decimated_wavelets_amd.sharded")
+        ov = os.environ.get("NDWT_BENCH_OVERLAP", "auto")        # A/B: 1 = always overlapped, 0 = exchange and compute in sequence
         eng = sh.ShardedNdDwt([a.wname] * d, sizes, pres_l2_norm=True, precision="single", group=None, device=dev,
-                              overlap=os.environ.get("NDWT_BENCH_OVERLAP", "1") == "1")   # 0: exchange and compute in sequence (A/B)
+                              overlap="auto" if ov == "auto" else ov == "1")
         x = torch.randn((eng.n_local,) + kshape[1:], device=dev, dtype=torch.float32)
+        if eng.overlap_mode == "auto":
+            eng.tune(x, level)                                    # untimed, before the warm-up: both schedules measured, the faster kept
         plan = eng.plan
         r_holder = {}
 
@@ -431,8 +466,10 @@ def main():
            "median_ms_per_step_hip_events": round(median_ms, 4),
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"{d}D fp32 {shape} {a.wname} {level} levels, dec+rec, pres_l2_norm, reference dilation (stride 1)",
-                      "sharding": "none" if world == 1 else f"outer-axis slabs x{world}; per level: analysis halo fetch (1 band) and synthesis "
-                                                              f"scatter-add (1 band) via RCCL send/recv, overlapped with the interior planes",
+                      "sharding": "none" if not sharded else f"outer-axis slabs x{world}; per level: analysis halo fetch (1 band) and synthesis "
+                                                             f"scatter-add (1 band) via RCCL send/recv; exchange "
+                                                             f"{'overlapped with the interior planes' if eng.overlap else 'then one launch per level'}"
+                                                             f" (overlap={eng.overlap_mode}, tune: {eng.tuned})",
                       "path": "per-axis" if a.generic else plan.describe(),
                       "coefficient_layout": ("pitched local slabs owned by the sharded driver" if sharded else
                                              "packed (reference)" if a.band_pitch == "packed" else "pitched bands (ndwt_band_pitch)")},
@@ -465,19 +502,36 @@ def main():
             except Exception as e:                                # (a box with less free memory than cfg5's 100 GB: say so, keep the line)
                 others[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
         out["other_configs"] = others
+        # one rank's share of the 8-GPU shardings of cfg3 / cfg4 on this GPU (no communication: the projection SURVEY 8e's >= 6x rests on)
+        try:
+            sh = importlib.import_module("non-decimated_wavelets_amd.sharded")
+            share = {"cfg3": one_rank_share(sh, torch, dev, "db4", 3, dts * 1e3)}
+            if "ms_per_step" in others.get("cfg4_transform", {}):
+                share["cfg4"] = one_rank_share(sh, torch, dev, "db6", 4, others["cfg4_transform"]["ms_per_step"])
+            out["one_rank_share"] = share
+        except Exception as e:
+            out["one_rank_share"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cores = os.cpu_count() or 1
-        workers = min(cores, 16)
-        if d == 2:
+        if a.cpu_full:
+            sample = list(sizes)                                  # the whole workload (512^3: ~160 GiB of host memory, minutes)
+        elif d == 2:
             sample = [4096, 4096] if cores >= 16 else [2048, 2048]
         elif d == 3:
             sample = [512, 512, 128] if cores >= 16 else [192, 192, 128]
         else:
             sample = [128, 128, 64, 32] if cores >= 16 else [64, 64, 32, 32]
-        v, secs = cpu_baseline(level, a.wname, sample, workers)
-        out["cpu_baseline"] = {"value": round(v, 2), "unit": "Mvoxels/s", "cores": workers, "host_cpu_count": cores, "kind": "port",
-                               "sample": f"{'x'.join(map(str, sample))} fp64/complex128 {a.wname} {level} levels dec+rec, FFT-domain "
-                                         f"restatement of mex/nddwt.c with scipy.fft workers={workers}; {secs:.1f} s"}
+        # the reference's own thread setting (fftw_plan_with_nthreads(8), mex/nddwt.c:103,146) AND every host core
+        w_ref = min(8, cores)
+        v, secs = cpu_baseline(level, a.wname, sample, w_ref)
+        desc = (f"{'x'.join(map(str, sample))} ({'the whole workload' if sample == list(sizes) else 'bounded sample of ' + shape}) fp64/complex128 "
+                f"{a.wname} {level} levels dec+rec, FFT-domain restatement of mex/nddwt.c (scipy.fft/pocketfft in place of FFTW)")
+        out["cpu_baseline"] = {"value": round(v, 2), "unit": "Mvoxels/s", "cores": w_ref, "host_cpu_count": cores, "kind": "port",
+                               "sample": f"{desc}; workers={w_ref} = the reference's fftw_plan_with_nthreads(8); {secs:.1f} s"}
+        if cores > w_ref:
+            v2, secs2 = cpu_baseline(level, a.wname, sample, cores)
+            out["cpu_baseline"]["all_cores"] = {"value": round(v2, 2), "unit": "Mvoxels/s", "cores": cores,
+                                                "sample": f"the same sample, workers={cores} (os.cpu_count()); {secs2:.1f} s"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist:

@@ -152,7 +152,7 @@ def _bands_in_place(y):
 
 class ShardedNdDwt:
     def __init__(self, wname, sizes, pres_l2_norm=False, precision="double", dilation="reference", group=None, device=None,
-                 engine=None, synthesis_scheme="auto", overlap=True, band_pitch="auto"):
+                 engine=None, synthesis_scheme="auto", overlap="auto", band_pitch="auto", _self_p2p=False):
         """band_pitch: layout of the coefficient slab dec() returns on the GPU -- 'auto' (default): the bands of one allocation, each
         contiguous, prod(local shape) + 256 bytes apart (a strided view: index it like any tensor; .contiguous() packs it; rec()
         takes either) -- the layout the synthesis kernels read 10 % faster; 'packed': a contiguous tensor, for
@@ -160,6 +160,10 @@ class ShardedNdDwt:
         if band_pitch not in ("auto", "packed"):
             raise ValueError("band_pitch must be 'auto' or 'packed'")
         self.band_pitch = band_pitch
+        # test hook: segments a rank owes ITSELF (the periodic wrap inside its own slab) go through the same grouped send / receive as
+        # the ones between ranks instead of a local copy -- a 1-rank `nccl` group then runs the whole RCCL branch (in-place halo
+        # receives, scatter_recv buffers, work.wait() ordering) on one GPU (tests/test_gpu_parity.py)
+        self._self_p2p = bool(_self_p2p)
         self.sizes = [int(s) for s in sizes]
         self.d = len(self.sizes)
         self.wname = [wname] * self.d if isinstance(wname, str) else list(wname)
@@ -190,8 +194,16 @@ class ShardedNdDwt:
         # staged through host copies.  RCCL ("nccl") sends the device buffers as they are.
         self._host_stage = bool(self.device.type == "cuda" and dist.is_initialized() and dist.get_backend(group) == "gloo")
         # overlap of the exchange with the planes that do not depend on it needs the run-of-planes entry points
-        self.overlap = bool(overlap and self.scheme == "scatter" and hasattr(self.engine, "analysis_run")
-                            and hasattr(self.engine, "synthesis_part") and getattr(self.engine, "supports_overlap", True))
+        self.can_overlap = bool(self.scheme == "scatter" and hasattr(self.engine, "analysis_run")
+                                and hasattr(self.engine, "synthesis_part") and getattr(self.engine, "supports_overlap", True))
+        # overlap: True / False, or "auto" = overlapped until tune() has measured both schedules on this machine.  The pieces cost
+        # (a slab level cut into interior + ends pays the (L-1)-plane march prologue twice more: cfg3's 64-plane slab 0.86 -> 0.97 ms per
+        # dec+rec on one MI355X), so they pay only where an exchange takes longer than that -- which depends on the fabric, not on us.
+        if overlap not in (True, False, "auto"):
+            raise ValueError("overlap must be True, False or 'auto'")
+        self.overlap_mode = overlap
+        self.overlap = bool(overlap) and self.can_overlap
+        self.tuned = None                       # tune(): {"overlap": chosen, "ms_overlap": t, "ms_one_piece": t}
 
     # ---------------------------------------------------------------------------------- plumbing
     def _owner(self, g):
@@ -260,15 +272,16 @@ class ShardedNdDwt:
                 continue
             dst = (hb if side == 0 else ha).narrow(ax, k0, n) if q == self.rank else None
             src = t.narrow(ax, l0, n) if p == self.rank else None
-            if p == self.rank and q == self.rank:                       # own planes (periodic wrap inside the slab)
+            if p == self.rank and q == self.rank and not self._self_p2p:   # own planes (periodic wrap inside the slab)
                 dst.copy_(src)
-            elif p == self.rank:
+                continue
+            if p == self.rank:
                 buf = src if src.is_contiguous() else src.contiguous()
                 if self._host_stage:
                     buf = buf.cpu()
                 keep.append(buf)
                 ops.append(dist.P2POp(dist.isend, buf, self._global_rank(q), self.group))
-            else:
+            if q == self.rank:
                 if dst.is_contiguous() and not self._host_stage:
                     ops.append(dist.P2POp(dist.irecv, dst, self._global_rank(p), self.group))
                 else:
@@ -295,14 +308,14 @@ class ShardedNdDwt:
         for q, side, p, k0, l0, n in self._plan_exchange(before, after):
             if q == self.rank:
                 part = parts[side].narrow(0, k0, n)                 # contiguous view
-                if p == self.rank:
+                if p == self.rank and not self._self_p2p:
                     adds_local.append((l0, n, part))
-                else:
-                    if self._host_stage:
-                        part = part.cpu()
-                        keep.append(part)
-                    ops.append(dist.P2POp(dist.isend, part, self._global_rank(p), self.group))
-            elif p == self.rank:
+                    continue
+                if self._host_stage:
+                    part = part.cpu()
+                    keep.append(part)
+                ops.append(dist.P2POp(dist.isend, part, self._global_rank(p), self.group))
+            if p == self.rank:
                 ref = parts[side]
                 if self._host_stage:
                     buf = torch.empty([n] + list(ref.shape[1:]), dtype=ref.dtype, device="cpu")
@@ -338,6 +351,43 @@ class ShardedNdDwt:
 
     def _stride(self, lev):
         return 1 if self.dilation == "reference" else 1 << (lev - 1)
+
+    def tune(self, x_local, level, steps=3):
+        """Measures dec + rec of this slab with the exchange overlapped (interior planes while the halo travels, then the ends) and in
+        one piece per level (exchange, then one launch), and keeps the faster schedule -- the same on every rank (the times are
+        MAX-reduced over the group, so all ranks take the same decision from the same numbers).  Collective: every rank of the group
+        must call it with its own slab and the same level.  Returns the record it stores in self.tuned."""
+        import time
+        if not self.can_overlap:
+            self.tuned = {"overlap": False, "ms_overlap": None, "ms_one_piece": None, "reason": "engine has no run-of-planes entry points"}
+            return self.tuned
+        distributed = dist.is_initialized() and self.world > 1
+        cuda = self.device.type == "cuda"
+
+        def fence():
+            if cuda:
+                torch.cuda.synchronize(self.device)
+            if distributed:
+                dist.barrier(self.group)
+
+        ms = {}
+        for mode in (True, False):
+            self.overlap = mode
+            self.rec(self.dec(x_local, level))            # buffers, plans, communicators of this schedule
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.rec(self.dec(x_local, level))
+            fence()
+            ms[mode] = (time.perf_counter() - t0) / steps * 1e3
+        if distributed:
+            red = torch.tensor([ms[True], ms[False]], dtype=torch.float64,
+                               device=self.device if dist.get_backend(self.group) == "nccl" else "cpu")
+            dist.all_reduce(red, op=dist.ReduceOp.MAX, group=self.group)
+            ms = {True: float(red[0]), False: float(red[1])}
+        self.overlap = ms[True] < ms[False]
+        self.tuned = {"overlap": self.overlap, "ms_overlap": round(ms[True], 4), "ms_one_piece": round(ms[False], 4), "steps": steps}
+        return self.tuned
 
     # --------------------------------------------------------------------------------- transform
     def dec(self, x_local, level):

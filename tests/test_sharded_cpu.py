@@ -123,6 +123,18 @@ def _worker(rank, world, port, sizes, wname, level, l2, dilation, scheme, q):
             # rec of arbitrary coefficients (not in the range of dec)
             r2 = eng.rec(ck[:, eng.z0:eng.z1].contiguous())
             e_rec2 = max(e_rec2, float(np.abs(r2.numpy() - want2[eng.z0:eng.z1]).max()))
+        if scheme == "scatter":
+            # overlap="auto" (the default): tune() times both schedules, MAX-reduces the times and every rank keeps the same one
+            eng = sh.ShardedNdDwt(wname, sizes, pres_l2_norm=l2, precision="double", dilation=dilation,
+                                  engine=OracleSlabEngine(wname, l2), synthesis_scheme=scheme)
+            assert eng.overlap_mode == "auto" and eng.overlap and eng.tuned is None
+            rec = eng.tune(xk[eng.z0:eng.z1].contiguous(), level, steps=1)
+            assert rec["overlap"] == eng.overlap and rec["ms_overlap"] > 0 and rec["ms_one_piece"] > 0
+            votes = [None] * world
+            dist.all_gather_object(votes, (rec["overlap"], rec["ms_overlap"], rec["ms_one_piece"]))
+            assert len(set(votes)) == 1, votes                 # one decision from one set of numbers
+            y_loc = eng.dec(xk[eng.z0:eng.z1].contiguous(), level)
+            e_dec = max(e_dec, float(np.abs(y_loc.numpy() - want[:, eng.z0:eng.z1]).max()))
         q.put((rank, e_dec, e_rec, e_rec2))
     finally:
         dist.destroy_process_group()
