@@ -184,8 +184,9 @@ def one_rank_share(sh, torch, dev, wname, level, whole_ms, n_local=64, steps=100
     x = torch.randn(n_local, 512, 512, device=dev, dtype=torch.float32)
     out = {"slab": f"512x512x{n_local} fp32 {wname} {level} levels, world size 1 (local-copy exchange)", "steps": steps,
            "whole_volume_ms": round(whole_ms, 4)}
-    for key, mode in (("one_piece", False), ("overlap", True)):
-        eng = sh.ShardedNdDwt([wname] * 3, [512, 512, n_local], pres_l2_norm=True, precision="single", device=dev, overlap=mode)
+    for key, mode, two in (("one_piece", False, False), ("overlap", True, False), ("overlap_two_streams", True, True)):
+        eng = sh.ShardedNdDwt([wname] * 3, [512, 512, n_local], pres_l2_norm=True, precision="single", device=dev, overlap=mode,
+                              two_streams=two)
         for _ in range(5):
             r = eng.rec(eng.dec(x, level))
         torch.cuda.synchronize(dev)

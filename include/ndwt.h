@@ -197,6 +197,15 @@ int ndwt_analysis_level_slab_runs(ndwt_plan* plan, const void* in_with_halo, voi
 int ndwt_synthesis_level_slab_runs(ndwt_plan* plan, const void* const* in_local, int64_t n_in, int64_t e0, int64_t e_stride,
                                    int64_t n_runs, int64_t n_out, void* out, int stride, void* stream);
 
+/* Up to NDWT_MAX_SEGMENTS runs of planes copied (op NDWT_SEG_COPY) or added (NDWT_SEG_ADD: dst[i] += src[i]) in ONE launch on
+ * `stream`, on the plan's device: the halo planes a slab takes from itself, and the partial sums received from the two neighbours
+ * added to the slab's edge planes -- a launch costs about 6 us on MI355X whatever it moves, and a level has two such runs.
+ * count[i] = elements (of the plan's scalar type; complex data: 2 per element) of run i; runs must not overlap each other. */
+#define NDWT_MAX_SEGMENTS 8
+#define NDWT_SEG_COPY 0
+#define NDWT_SEG_ADD 1
+int ndwt_slab_segments(ndwt_plan* plan, int op, int nseg, void* const* dst, const void* const* src, const int64_t* count, void* stream);
+
 /* ---- single-process multi-device plan (hard part 5; section 8b `devices[]`) ---------------------------
  * The reference's host is ONE process calling one gateway (nd_dwt_3D.m:161,225): this is the multi-GPU path that fits behind
  * that call.  The volume is sharded in slabs on its outermost axis over devices[0..ndev) (a device may appear more than once:

@@ -27,7 +27,7 @@ EXPORTS = [
     "ndwt_analysis_level_slab_split", "ndwt_synthesis_level_slab_ext", "ndwt_analysis_level_slab_part",
     "ndwt_synthesis_level_slab_part", "ndwt_analysis_level_slab_runs", "ndwt_synthesis_level_slab_runs", "ndwt_last_error",
     "ndwt_version", "ndwt_mplan_create", "ndwt_mplan_destroy", "ndwt_mplan_num_slabs", "ndwt_mplan_slab", "ndwt_mdec_host",
-    "ndwt_mrec_host", "ndwt_mplan_last_error", "ndwt_mdec", "ndwt_mrec", "ndwt_mplan_set_exchange", "ndwt_mplan_describe", "ndwt_plan_slab_fast", "ndwt_dec_pitched", "ndwt_rec_pitched", "ndwt_shrink_pitched", "ndwt_band_pitch",
+    "ndwt_mrec_host", "ndwt_mplan_last_error", "ndwt_mdec", "ndwt_mrec", "ndwt_mplan_set_exchange", "ndwt_mplan_describe", "ndwt_plan_slab_fast", "ndwt_dec_pitched", "ndwt_rec_pitched", "ndwt_shrink_pitched", "ndwt_band_pitch", "ndwt_slab_segments",
 ]
 
 
@@ -125,6 +125,8 @@ def lib() -> ctypes.CDLL:
     L.ndwt_mplan_set_exchange.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.ndwt_mplan_describe.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
     L.ndwt_plan_slab_fast.argtypes = [ctypes.c_void_p]
+    L.ndwt_slab_segments.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, c_void_pp, c_void_pp, ctypes.POINTER(ctypes.c_int64),
+                                     ctypes.c_void_p]
     L.ndwt_last_error.restype = ctypes.c_char_p
     L.ndwt_version.restype = ctypes.c_char_p
     _lib = L

@@ -136,6 +136,12 @@ class Plan:
     def rec_split_host(self, y_re, y_im, x_re, x_im, level):
         L.check(L.lib().ndwt_rec_split_host(self._h, y_re, y_im, x_re, x_im, int(level)))
 
+    def slab_segments(self, add, dsts, srcs, counts, stream=0):
+        """up to 8 runs of elements copied (add=False) or added (dst += src) in one launch (include/ndwt.h: ndwt_slab_segments)"""
+        n = len(dsts)
+        L.check(L.lib().ndwt_slab_segments(self._h, 1 if add else 0, n, (ctypes.c_void_p * n)(*dsts), (ctypes.c_void_p * n)(*srcs),
+                                           (ctypes.c_int64 * n)(*counts), ctypes.c_void_p(stream)))
+
     def slab_halo(self, stride=1):
         v = [ctypes.c_int64(0) for _ in range(4)]
         L.check(L.lib().ndwt_slab_halo(self._h, int(stride), *[ctypes.byref(t) for t in v]))

@@ -954,6 +954,52 @@ static int slab_synthesis_runs_impl(ndwt_plan* p, int Lp, const void* const* in,
 }
 
 // ------------------------------------------------------------------------------------------ C ABI
+// ---- several runs of planes copied / added in one launch (include/ndwt.h: ndwt_slab_segments) ----
+namespace {
+struct SegArgs {
+    void* dst[NDWT_MAX_SEGMENTS];
+    const void* src[NDWT_MAX_SEGMENTS];
+    long long count[NDWT_MAX_SEGMENTS];      // in units of V
+};
+// blockIdx.y = run; 16-byte accesses (V = 4 floats / 2 doubles) where every run allows them, scalars otherwise
+template <typename V, bool ADD>
+__global__ __launch_bounds__(256) void segments_kernel(const SegArgs a) {
+    V* __restrict__ d = (V*)a.dst[blockIdx.y];
+    const V* __restrict__ s = (const V*)a.src[blockIdx.y];
+    const long long n = a.count[blockIdx.y], step = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+        if constexpr (ADD) d[i] = d[i] + s[i];
+        else d[i] = s[i];
+    }
+}
+template <typename T> int segments_launch(int op, int nseg, void* const* dst, const void* const* src, const int64_t* count, hipStream_t st) {
+    typedef typename VecT<T>::v4 V4;
+    constexpr int per = 16 / (int)sizeof(T);
+    bool vec = true;
+    long long most = 0;
+    for (int i = 0; i < nseg; ++i) {
+        vec = vec && count[i] % per == 0 && (uintptr_t)dst[i] % 16 == 0 && (uintptr_t)src[i] % 16 == 0;
+        if (count[i] > most) most = count[i];
+    }
+    SegArgs a;
+    memset(&a, 0, sizeof a);
+    for (int i = 0; i < nseg; ++i) { a.dst[i] = dst[i]; a.src[i] = src[i]; a.count[i] = vec ? count[i] / per : count[i]; }
+    long long bx = ((vec ? most / per : most) + 255) / 256;
+    if (bx < 1) bx = 1;
+    if (bx > 2048) bx = 2048;
+    const dim3 grid((unsigned)bx, (unsigned)nseg);
+    if (sizeof(T) == 4) {
+        if (vec) { if (op) hipLaunchKernelGGL((segments_kernel<V4, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((segments_kernel<V4, false>), grid, dim3(256), 0, st, a); }
+        else { if (op) hipLaunchKernelGGL((segments_kernel<T, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((segments_kernel<T, false>), grid, dim3(256), 0, st, a); }
+    } else {
+        typedef typename VecT<T>::v2 V2;
+        if (vec) { if (op) hipLaunchKernelGGL((segments_kernel<V2, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((segments_kernel<V2, false>), grid, dim3(256), 0, st, a); }
+        else { if (op) hipLaunchKernelGGL((segments_kernel<T, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((segments_kernel<T, false>), grid, dim3(256), 0, st, a); }
+    }
+    return (int)hipGetLastError();
+}
+}  // namespace
+
 extern "C" {
 
 int ndwt_wave_filters(const char* wname, double* lo_d, double* hi_d, int* len) {
@@ -1635,6 +1681,21 @@ int ndwt_plan_set_stamps(ndwt_plan* p, void* dev_buffer) {
 #endif
 
 const char* ndwt_last_error(void) { return g_last_error.c_str(); }
+int ndwt_slab_segments(ndwt_plan* p, int op, int nseg, void* const* dst, const void* const* src, const int64_t* count, void* stream) {
+    if (!p) return fail(NDWT_ERR_INVALID_ARG, "null plan");
+    if (op != NDWT_SEG_COPY && op != NDWT_SEG_ADD) return fail(NDWT_ERR_INVALID_ARG, "op must be NDWT_SEG_COPY or NDWT_SEG_ADD");
+    if (nseg < 0 || nseg > NDWT_MAX_SEGMENTS) return fail(NDWT_ERR_INVALID_ARG, "at most %d runs per call", NDWT_MAX_SEGMENTS);
+    if (nseg == 0) return NDWT_OK;
+    if (!dst || !src || !count) return fail(NDWT_ERR_INVALID_ARG, "null argument");
+    for (int i = 0; i < nseg; ++i)
+        if (!dst[i] || !src[i] || count[i] < 0) return fail(NDWT_ERR_INVALID_ARG, "run %d: null pointer or negative count", i);
+    HIP_TRY(hipSetDevice(p->device));
+    const int rc = p->dtype == NDWT_F32 ? segments_launch<float>(op, nseg, dst, src, count, (hipStream_t)stream)
+                                        : segments_launch<double>(op, nseg, dst, src, count, (hipStream_t)stream);
+    if (rc != 0) return fail(NDWT_ERR_HIP, "segment kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return NDWT_OK;
+}
+
 const char* ndwt_version(void) { return "ndwt-hip 0.1 (gfx950)"; }
 
 }  // extern "C"

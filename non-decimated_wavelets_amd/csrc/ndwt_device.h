@@ -1713,6 +1713,31 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
             }
         NDWT_SEND
     }
+    // the store of the pending sum in slot R as it is (the z stage of an iteration whose inputs are all zero)
+    template <int R> static NDWT_DEV void zemit(State& st, Shared& sh, const Args& a, long long obase, int z, int tid) {
+        NDWT_SFOR(k, NYI)
+            const int it = tid + k * NT;
+            if (it < YITEMS && st.ostore[k]) {
+                v2 o;
+                if constexpr (R < L - ZLDS) o = st.zacc[k][R];
+                else o = sh.zl[R - (L - ZLDS)][it];
+                T* dst = a.out[0] + obase + (long long)z * a.plane;   // wave-uniform
+                if constexpr (VEC4) {
+                    gstore<v2>(dst, st.ooff[k], o, a.nt);
+                } else if (st.ostore[k] == 2) {
+                    gstore<typename VecT<T>::v2u>(dst, st.ooff[k], o, 0);
+                } else {
+                    gstore<T>(dst, st.ooff[k], o.x, 0);
+                }
+            }
+        NDWT_SEND
+    }
+    template <int R> static NDWT_DEV void zemit_dispatch(int r, State& st, Shared& sh, const Args& a, long long obase, int z, int tid) {
+        if constexpr (R < L) {
+            if (r == R) zemit<R>(st, sh, a, obase, z, tid);
+            else zemit_dispatch<R + 1>(r, st, sh, a, obase, z, tid);
+        }
+    }
     template <int R>
     static NDWT_DEV void zdispatch(int r, State& st, Shared& sh, const RegTaps& tp, const Args& a, long long obase, int z, bool emit, int tid) {
         if constexpr (R < L) {
@@ -1739,19 +1764,39 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
         const int zsh = tc.batch * a.zbs;
         const int nsteps = tc.zend - tc.zbeg;
         const int nplanes = nsteps + L - 1;              // planes zbeg-LH .. zend-1+RH
+        // Zero-extended slab (z_wrap 3): input plane zm = zbeg + p - (L-1) of iteration p exists for zlo <= zm + zsh < zhi only.  The
+        // iterations before the first such plane are skipped (at most L-1 of them: those complete no output plane), the ones after the
+        // last run the z stage alone (they only add zeros to the pending sums and emit them) -- a run of m planes at the end of a slab
+        // costs m full iterations instead of m + L-1 (the partial sums a rank owes its neighbours: 45 -> see DESIGN.md section 5).
+        int p0 = 0, pend = nplanes;                      // iterations [p0, pend): x, y and z stages; [pend, nplanes): z stage only
+        if (a.z_wrap == 3) {
+            const int first = a.zlo - zsh - tc.zbeg + (L - 1), last = a.zhi - zsh - tc.zbeg + (L - 1);
+            p0 = first < 0 ? 0 : (first > L - 1 ? L - 1 : first);
+            pend = last < p0 ? p0 : (last > nplanes ? nplanes : last);
+        }
+        const int zb0 = tc.zbeg - LH + p0;               // the plane iteration p0 reads; iteration p0 + i reads zb0 + i
+        const int np = pend - p0;
         ex.each([&](int tid, State& st) __attribute__((always_inline)) {
             setup(st, a, tc, tid);
-            load_raw<0>(st, a, ibase, tc.zbeg - LH, zsh);
+            NDWT_SFOR(k, NYI)                             // (a march that starts at p0 > 0 never ran the first taps of the sums pending then)
+                NDWT_SFOR(j, L - ZLDS)
+                    st.zacc[k][j] = (v2)(T(0));
+                NDWT_SEND
+                NDWT_SFOR(j, ZLDS)
+                    if (tid + k * NT < YITEMS) sh.zl[j][tid + k * NT] = (v2)(T(0));
+                NDWT_SEND
+            NDWT_SEND
+            if (np > 0) load_raw<0>(st, a, ibase, zb0, zsh);
             if constexpr (DEPTH == 2) {
-                if (nplanes > 1) load_raw<1>(st, a, ibase, tc.zbeg - LH + 1, zsh);
+                if (np > 1) load_raw<1>(st, a, ibase, zb0 + 1, zsh);
             }
         });
-        // the y and z stages of plane p (x-synthesised tile in xs[p & 1]) at raised priority: they are short and end in the
+        // the y and z stages of iteration p (x-synthesised tile in xs[buf]) at raised priority: they are short and end in the
         // plane's store, and under oldest-first arbitration the youngest waves' store waits behind the older waves' queued loads
-        auto yz = [&](int p) __attribute__((always_inline)) {
+        auto yz = [&](int p, int buf) __attribute__((always_inline)) {
             const int s = p - (L - 1);                   // output plane this input plane completes (if >= 0)
             NDWT_SETPRIO(1);
-            ex.each([&](int tid, State& st) __attribute__((always_inline)) { ysyn(st, sh, tp, p & 1, tid); });
+            ex.each([&](int tid, State& st) __attribute__((always_inline)) { ysyn(st, sh, tp, buf, tid); });
             NDWT_TL(3)
             ex.each([&](int tid, State& st) __attribute__((always_inline)) {
                 zdispatch<0>((p + 1) % L, st, sh, tp, a, obase, tc.zbeg + s, s >= 0, tid);
@@ -1760,39 +1805,41 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
             NDWT_TL(4)
         };
         if constexpr (DEPTH == 1) {
-            // per plane:  x-synth(p) from registers -> xs[p&1] ; refill with plane p+1 ; barrier ; y/z(p) from xs[p&1]
-            for (int p = 0; p < nplanes; ++p) {
+            // per plane:  x-synth(i) from registers -> xs[i&1] ; refill with plane i+1 ; barrier ; y/z(i) from xs[i&1]
+            for (int i = 0; i < np; ++i) {
+                const int p = p0 + i;
                 NDWT_TL(0)
                 ex.each([&](int, State& st) __attribute__((always_inline)) { shrink_raw<0>(st, a); });
-                ex.each([&](int tid, State& st) __attribute__((always_inline)) { xsyn<0>(ex, st, sh, tp, p & 1, tid); });
+                ex.each([&](int tid, State& st) __attribute__((always_inline)) { xsyn<0>(ex, st, sh, tp, i & 1, tid); });
                 NDWT_TL(1)
                 ex.each([&](int, State& st) __attribute__((always_inline)) {
-                    if (p + 1 < nplanes) load_raw<0>(st, a, ibase, tc.zbeg - LH + p + 1, zsh);
+                    if (i + 1 < np) load_raw<0>(st, a, ibase, zb0 + i + 1, zsh);
                 });
                 NDWT_TL(2)
                 ex.barrier();
-                yz(p);
+                yz(p, i & 1);
             }
-        } else {
+        } else if (np > 0) {
             // Two register sets, refilled at TWO DIFFERENT POINTS of the plane.  A wave stalls on its own loads until the pipe
             // has accepted them; when every wave refills after its x stage the pipe idles from the barrier until the first
             // x stage ends, and the workgroup then waits for the last wave's loads to be accepted.  Half of the waves refill
             // at the START of an iteration (the set their previous x stage freed), the others right after their x stage.
-            //   iteration p (parity Q): early waves: set Q <- plane p+2 ; y/z(p) ; x(p+1) from set 1-Q ; late waves: set 1-Q <- plane p+3 ; barrier
-            auto iter = [&](auto q_c, int p) __attribute__((always_inline)) {
+            //   iteration i (parity Q): early waves: set Q <- plane i+2 ; y/z(i) ; x(i+1) from set 1-Q ; late waves: set 1-Q <- plane i+3 ; barrier
+            auto iter = [&](auto q_c, int i) __attribute__((always_inline)) {
                 constexpr int Q = decltype(q_c)::value;
+                const int p = p0 + i;
                 NDWT_TL(0)
                 ex.each([&](int tid, State& st) __attribute__((always_inline)) {
-                    if (early_refill(tid) && p + 2 < nplanes) load_raw<Q>(st, a, ibase, tc.zbeg - LH + p + 2, zsh);
+                    if (early_refill(tid) && i + 2 < np) load_raw<Q>(st, a, ibase, zb0 + i + 2, zsh);
                 });
                 NDWT_TL(1)
-                yz(p);
-                if (p + 1 < nplanes) {
+                yz(p, Q);
+                if (i + 1 < np) {
                     ex.each([&](int, State& st) __attribute__((always_inline)) { shrink_raw<1 - Q>(st, a); });
                     ex.each([&](int tid, State& st) __attribute__((always_inline)) { xsyn<1 - Q>(ex, st, sh, tp, 1 - Q, tid); });
                     NDWT_TL(2)
                     ex.each([&](int tid, State& st) __attribute__((always_inline)) {
-                        if (!early_refill(tid) && p + 3 < nplanes) load_raw<1 - Q>(st, a, ibase, tc.zbeg - LH + p + 3, zsh);
+                        if (!early_refill(tid) && i + 3 < np) load_raw<1 - Q>(st, a, ibase, zb0 + i + 3, zsh);
                     });
                 }
                 NDWT_TL(5)
@@ -1802,13 +1849,19 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
             ex.each([&](int, State& st) __attribute__((always_inline)) { shrink_raw<0>(st, a); });
             ex.each([&](int tid, State& st) __attribute__((always_inline)) { xsyn<0>(ex, st, sh, tp, 0, tid); });
             ex.each([&](int tid, State& st) __attribute__((always_inline)) {
-                if (!early_refill(tid) && 2 < nplanes) load_raw<0>(st, a, ibase, tc.zbeg - LH + 2, zsh);
+                if (!early_refill(tid) && 2 < np) load_raw<0>(st, a, ibase, zb0 + 2, zsh);
             });
             ex.barrier();
-            for (int p = 0; p < nplanes; p += 2) {
-                iter(std::integral_constant<int, 0>{}, p);
-                if (p + 1 < nplanes) iter(std::integral_constant<int, 1>{}, p + 1);
+            for (int i = 0; i < np; i += 2) {
+                iter(std::integral_constant<int, 0>{}, i);
+                if (i + 1 < np) iter(std::integral_constant<int, 1>{}, i + 1);
             }
+        }
+        // the iterations past the last plane of a zero-extended slab: nothing to synthesise in x and y, and the z stage would add zeros
+        // to the pending sums -- what is left of it is the store of the sum each iteration completes (slot (p + 1) % L, zsyn)
+        for (int p = pend; p < nplanes; ++p) {
+            const int s = p - (L - 1);
+            if (s >= 0) ex.each([&](int tid, State& st) __attribute__((always_inline)) { zemit_dispatch<0>((p + 1) % L, st, sh, a, obase, tc.zbeg + s, tid); });
         }
     }
 };

@@ -37,7 +37,7 @@ constexpr int kInv3YTX = 64, kInv3YTY = 32;
 // 10 taps as they are, and for 12 taps with 6 of the 12 pending z sums in LDS (Inv3Y::ZLDS): 512^3 db6 1.37 -> 1.30 ms per launch.
 // (4 and 6 taps fit the same way -- 2 / 4 sums in LDS -- and run SLOWER than one register set: 1.05 vs 1.02, 1.18 vs 1.08 ms.)
 // 18 and 20 taps (one register set): 8 of the pending z sums in LDS -- without them the instances spill 7 .. 19 registers.
-constexpr int inv3y_zlds(int L, int depth, int ew = 1) { return ew != 1 ? 0 : (depth == 2 && L == 12) ? 6 : (L >= 18 ? 8 : 0); }
+constexpr int inv3y_zlds(int L, int depth, int ew = 1) { return ew != 1 ? 0 : (depth == 2 && L == 12) ? 6 : (depth == 2 && L == 10) ? 2 : (L >= 18 ? 8 : 0); }
 // A level dilated by 4 (ew = 4, TX in scalars, up to 8 taps): the x halo is L - 1 whole lanes; 8 taps: 23 lanes per haloed row, two rows per
 // wave, 32 haloed rows -> 64 x 24.
 constexpr int inv3y_ty(int L, int ew = 1) { return ew == 4 ? (L <= 6 ? kInv3YTY : 24) : ew == 2 ? kInv3YTY : (L <= 16 ? kInv3YTY : (L <= 18 ? 24 : 28)); }

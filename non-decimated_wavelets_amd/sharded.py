@@ -64,6 +64,15 @@ class HipSlabEngine:
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def segments(self, add, pairs):
+        """pairs of equally shaped contiguous tensors (dst, src): dst = src or dst += src, all pairs in ONE launch (a launch costs ~6 us
+        whatever it moves; a level has two such runs: the planes a slab takes from itself, the partial sums of the two neighbours)"""
+        scal = 2 if pairs[0][0].is_complex() else 1
+        for i in range(0, len(pairs), 8):
+            part = pairs[i:i + 8]
+            self.plan.slab_segments(add, [d.data_ptr() for d, _ in part], [s.data_ptr() for _, s in part],
+                                    [d.numel() * scal for d, _ in part], self._stream())
+
     def analysis(self, in_with_halo, outs, stride):
         self.plan.analysis_level_slab(in_with_halo.data_ptr(), [o.data_ptr() for o in outs], stride, self._stream())
 
@@ -152,7 +161,7 @@ def _bands_in_place(y):
 
 class ShardedNdDwt:
     def __init__(self, wname, sizes, pres_l2_norm=False, precision="double", dilation="reference", group=None, device=None,
-                 engine=None, synthesis_scheme="auto", overlap="auto", band_pitch="auto", _self_p2p=False):
+                 engine=None, synthesis_scheme="auto", overlap="auto", band_pitch="auto", two_streams=False, _self_p2p=False):
         """band_pitch: layout of the coefficient slab dec() returns on the GPU -- 'auto' (default): the bands of one allocation, each
         contiguous, prod(local shape) + 256 bytes apart (a strided view: index it like any tensor; .contiguous() packs it; rec()
         takes either) -- the layout the synthesis kernels read 10 % faster; 'packed': a contiguous tensor, for
@@ -203,7 +212,13 @@ class ShardedNdDwt:
             raise ValueError("overlap must be True, False or 'auto'")
         self.overlap_mode = overlap
         self.overlap = bool(overlap) and self.can_overlap
-        self.tuned = None                       # tune(): {"overlap": chosen, "ms_overlap": t, "ms_one_piece": t}
+        # the pieces of an overlapped level are independent of each other (the ends wait for the exchange, the interior does not): on the
+        # GPU the edge pieces and the exchange they feed / wait for go to a high-priority side stream, the big piece stays on the
+        # caller's stream, and the two meet at the end of the level -- the small launch then hides in the big one's ramp and tail
+        # instead of adding its own (one MI355X, cfg3's slab: see DESIGN.md section 5)
+        self.two_streams = bool(two_streams) and self.device.type == "cuda"
+        self._side = None
+        self.tuned = None                       # tune(): {"schedule": chosen, "ms_<schedule>": t, ...}
 
     # ---------------------------------------------------------------------------------- plumbing
     def _owner(self, g):
@@ -266,14 +281,14 @@ class ShardedNdDwt:
             hb = t.new_empty(shp[:ax] + [before] + shp[ax + 1:])
         if ha is None:
             ha = t.new_empty(shp[:ax] + [after] + shp[ax + 1:])
-        ops, keep, post = [], [], []
+        ops, keep, post, local = [], [], [], []
         for q, side, p, k0, l0, n in self._plan_exchange(before, after):
             if p != self.rank and q != self.rank:
                 continue
             dst = (hb if side == 0 else ha).narrow(ax, k0, n) if q == self.rank else None
             src = t.narrow(ax, l0, n) if p == self.rank else None
             if p == self.rank and q == self.rank and not self._self_p2p:   # own planes (periodic wrap inside the slab)
-                dst.copy_(src)
+                local.append((dst, src))
                 continue
             if p == self.rank:
                 buf = src if src.is_contiguous() else src.contiguous()
@@ -288,6 +303,7 @@ class ShardedNdDwt:
                     buf = torch.empty(dst.shape, dtype=dst.dtype, device="cpu" if self._host_stage else dst.device)
                     ops.append(dist.P2POp(dist.irecv, buf, self._global_rank(p), self.group))
                     post.append(lambda dst=dst, buf=buf: dst.copy_(buf))
+        self._apply(False, local)
         works = dist.batch_isend_irecv(ops) if ops else []
         return hb, ha, (works, post, keep)
 
@@ -330,8 +346,32 @@ class ShardedNdDwt:
         works, adds, _keep = pending
         for w in works:
             w.wait()
-        for l0, n, buf in adds:
-            own.narrow(0, l0, n).add_(buf if buf.device == own.device else buf.to(own.device))
+        self._apply(True, [(own.narrow(0, l0, n), buf if buf.device == own.device else buf.to(own.device)) for l0, n, buf in adds])
+
+    def _apply(self, add, pairs):
+        """dst = src / dst += src for every pair; engines with a multi-run kernel take all contiguous pairs in one launch"""
+        if not pairs:
+            return
+        seg = getattr(self.engine, "segments", None)
+        if seg is not None and pairs[0][0].is_cuda and all(d.is_contiguous() and s.is_contiguous() and d.dtype == s.dtype for d, s in pairs):
+            # one launch per batch of runs whose destinations are disjoint: a slab thinner than the halo gets several addends for the
+            # same planes (multi-hop exchange), and those must be added one after the other
+            batch, spans = [], []
+            for d, s_ in pairs:
+                lo = d.data_ptr()
+                hi = lo + d.numel() * d.element_size()
+                if any(lo < h and l < hi for l, h in spans):
+                    seg(add, batch)
+                    batch, spans = [], []
+                batch.append((d, s_))
+                spans.append((lo, hi))
+            seg(add, batch)
+            return
+        for d, s in pairs:
+            if add:
+                d.add_(s)
+            else:
+                d.copy_(s)
 
     def _one_stream(self):
         """The driver's scratch buffers (halo margins, partial sums, receive buffers) are reused across calls and every hazard on
@@ -346,6 +386,11 @@ class ShardedNdDwt:
             cur.wait_event(last.record_event())
         self._last_stream = cur
 
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device, priority=-1)
+        return self._side
+
     def _global_rank(self, r):
         return r if self.group is None or self.group is dist.group.WORLD else dist.get_global_rank(self.group, r)
 
@@ -353,13 +398,14 @@ class ShardedNdDwt:
         return 1 if self.dilation == "reference" else 1 << (lev - 1)
 
     def tune(self, x_local, level, steps=3):
-        """Measures dec + rec of this slab with the exchange overlapped (interior planes while the halo travels, then the ends) and in
-        one piece per level (exchange, then one launch), and keeps the faster schedule -- the same on every rank (the times are
-        MAX-reduced over the group, so all ranks take the same decision from the same numbers).  Collective: every rank of the group
-        must call it with its own slab and the same level.  Returns the record it stores in self.tuned."""
+        """Measures dec + rec of this slab under the three schedules -- one piece per level (exchange, then one launch), the exchange
+        overlapped with the interior planes on one stream, the same with the edge pieces and the exchange on a high-priority side
+        stream -- and keeps the fastest; the same on every rank (the times are MAX-reduced over the group, so all ranks take the same
+        decision from the same numbers).  Collective: every rank of the group calls it with its own slab and the same level.
+        Returns the record it stores in self.tuned."""
         import time
         if not self.can_overlap:
-            self.tuned = {"overlap": False, "ms_overlap": None, "ms_one_piece": None, "reason": "engine has no run-of-planes entry points"}
+            self.tuned = {"schedule": "one_piece", "reason": "engine has no run-of-planes entry points"}
             return self.tuned
         distributed = dist.is_initialized() and self.world > 1
         cuda = self.device.type == "cuda"
@@ -370,23 +416,24 @@ class ShardedNdDwt:
             if distributed:
                 dist.barrier(self.group)
 
-        ms = {}
-        for mode in (True, False):
-            self.overlap = mode
+        modes = [("one_piece", False, False), ("overlap", True, False)] + ([("overlap_two_streams", True, True)] if cuda else [])
+        ms = []
+        for _, ov, ts in modes:
+            self.overlap, self.two_streams = ov, ts
             self.rec(self.dec(x_local, level))            # buffers, plans, communicators of this schedule
             fence()
             t0 = time.perf_counter()
             for _ in range(steps):
                 self.rec(self.dec(x_local, level))
             fence()
-            ms[mode] = (time.perf_counter() - t0) / steps * 1e3
+            ms.append((time.perf_counter() - t0) / steps * 1e3)
         if distributed:
-            red = torch.tensor([ms[True], ms[False]], dtype=torch.float64,
-                               device=self.device if dist.get_backend(self.group) == "nccl" else "cpu")
+            red = torch.tensor(ms, dtype=torch.float64, device=self.device if dist.get_backend(self.group) == "nccl" else "cpu")
             dist.all_reduce(red, op=dist.ReduceOp.MAX, group=self.group)
-            ms = {True: float(red[0]), False: float(red[1])}
-        self.overlap = ms[True] < ms[False]
-        self.tuned = {"overlap": self.overlap, "ms_overlap": round(ms[True], 4), "ms_one_piece": round(ms[False], 4), "steps": steps}
+            ms = [float(v) for v in red]
+        best = min(range(len(modes)), key=lambda i: ms[i])
+        _, self.overlap, self.two_streams = modes[best]
+        self.tuned = {"schedule": modes[best][0], "steps": steps, **{f"ms_{m[0]}": round(t, 4) for m, t in zip(modes, ms)}}
         return self.tuned
 
     # --------------------------------------------------------------------------------- transform
@@ -433,15 +480,27 @@ class ShardedNdDwt:
                 ha_dst = self._buf(("halo_a", lev & 1), (aa,) + inner, x_local)
             if overlap:
                 # interior planes [ab, n-aa) read the slab only: run them while the halo planes travel
-                hb, ha, pending = self._start_fetch_halo(cur, 0, ab, aa, hb_dst, ha_dst)
-                self.engine.analysis_run(cur, hb, ha, outs, ab, n - aa, s)
-                self._finish_exchange(pending)
-                if cur_buf is not None and hasattr(self.engine, "analysis_ends"):
-                    self.engine.analysis_ends(cur_buf, outs, s)           # both ends, one launch
+                def ends(pending, hb, ha):
+                    self._finish_exchange(pending)
+                    if cur_buf is not None and hasattr(self.engine, "analysis_ends"):
+                        self.engine.analysis_ends(cur_buf, outs, s)           # both ends, one launch
+                    else:
+                        if ab:
+                            self.engine.analysis_run(cur, hb, ha, outs, 0, ab, s)
+                        self.engine.analysis_run(cur, hb, ha, outs, n - aa, n, s)
+                if self.two_streams:
+                    main, side = torch.cuda.current_stream(self.device), self._side_stream()
+                    side.wait_stream(main)                                # the level's input is complete
+                    with torch.cuda.stream(side):                         # exchange + ends: the side stream (the exchange waits for it)
+                        hb, ha, pending = self._start_fetch_halo(cur, 0, ab, aa, hb_dst, ha_dst)
+                    self.engine.analysis_run(cur, hb, ha, outs, ab, n - aa, s)
+                    with torch.cuda.stream(side):
+                        ends(pending, hb, ha)
+                    main.wait_stream(side)
                 else:
-                    if ab:
-                        self.engine.analysis_run(cur, hb, ha, outs, 0, ab, s)
-                    self.engine.analysis_run(cur, hb, ha, outs, n - aa, n, s)
+                    hb, ha, pending = self._start_fetch_halo(cur, 0, ab, aa, hb_dst, ha_dst)
+                    self.engine.analysis_run(cur, hb, ha, outs, ab, n - aa, s)
+                    ends(pending, hb, ha)
             else:
                 hb, ha, pending = self._start_fetch_halo(cur, 0, ab, aa, hb_dst, ha_dst)
                 self._finish_exchange(pending)
@@ -470,16 +529,27 @@ class ShardedNdDwt:
                 # the partial sums owed to the neighbours first (sa planes ahead of the slab, sb behind it: they depend
                 # on the first / last coefficient planes only), then the slab's own planes while those travel
                 n, inner = self.n_local, tuple(prev.shape[1:])
-                if hasattr(self.engine, "synthesis_send_parts"):
-                    part_b, part_a = self.engine.synthesis_send_parts(ins, s)
-                else:
-                    part_b, part_a = prev.new_empty((sa,) + inner), prev.new_empty((sb,) + inner)
-                    if sa:
-                        self.engine.synthesis_part(ins, 0, part_b, s)
-                    self.engine.synthesis_part(ins, sa + n, part_a, s)
-                pending = self._start_scatter(part_b, part_a, sa, sb)
+
+                def send_parts():
+                    if hasattr(self.engine, "synthesis_send_parts"):
+                        part_b, part_a = self.engine.synthesis_send_parts(ins, s)
+                    else:
+                        part_b, part_a = prev.new_empty((sa,) + inner), prev.new_empty((sb,) + inner)
+                        if sa:
+                            self.engine.synthesis_part(ins, 0, part_b, s)
+                        self.engine.synthesis_part(ins, sa + n, part_a, s)
+                    return self._start_scatter(part_b, part_a, sa, sb)
                 own = prev.new_empty((n,) + inner) if lev == 1 else self._buf(("syn_own", lev & 1), (n,) + inner, prev)
-                self.engine.synthesis_part(ins, sa, own, s)
+                if self.two_streams:
+                    main, side = torch.cuda.current_stream(self.device), self._side_stream()
+                    side.wait_stream(main)                                # the level's coefficients are complete
+                    with torch.cuda.stream(side):                         # partial sums + their exchange: the side stream
+                        pending = send_parts()
+                    self.engine.synthesis_part(ins, sa, own, s)           # the slab's own planes meanwhile
+                    main.wait_stream(side)                                # (the partial sums this rank owes itself)
+                else:
+                    pending = send_parts()
+                    self.engine.synthesis_part(ins, sa, own, s)
                 self._finish_scatter(pending, own)
                 prev = own
             elif self.scheme == "scatter":

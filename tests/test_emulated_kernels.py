@@ -140,6 +140,41 @@ def test_emulated_pair_packed_synthesis(emu, sizes, wn, vec4, zchunk, small, l2)
         assert np.abs(got - want).max() <= 2e-6 * max(np.abs(want).max(), 1.0), variant
 
 
+@pytest.mark.slow
+@pytest.mark.parametrize("sizes,wn,vec4,zchunk,small", [
+    ((16, 9, 7), ("db1", "db3", "db1"), True, 0, True),
+    ((20, 17, 12), ("db4", "db4", "db4"), True, 5, True),          # chunks of 5: leading zero iterations, a middle chunk, trailing ones
+    ((20, 17, 12), ("db4", "db4", "db4"), True, 2, True),          # chunks shorter than the filter: every chunk starts or ends in zeros
+    ((24, 19, 4), ("db6", "db2", "db4"), True, 0, True),           # a slab thinner than the filter (cfg5's regime)
+    ((21, 14, 12), ("db5", "db3", "db1"), False, 5, True),
+    ((68, 39, 9), ("db4", "db4", "db4"), True, 4, False),          # production tile
+    ((72, 37, 10), ("db6", "db6", "db6"), True, 0, False),
+    ((24, 22, 9), ("db10", "db10", "db10"), True, 6, True),        # pending z sums in LDS
+])
+def test_emulated_pair_packed_synthesis_of_a_zero_extended_slab(emu, sizes, wn, vec4, zchunk, small):
+    """Inv3Y with z_wrap = 3 (the scatter-add synthesis of a slab: the coefficient planes outside the slab read as zero): the march
+    skips the iterations before the first plane of the slab and only emits the pending sums after the last one -- same numbers as
+    the periodic oracle on the zero-padded slab, and the planes past the slab are never read (they hold NaN here)"""
+    rng = np.random.default_rng(21)
+    n1, n2, n_in = sizes
+    filt = [orc.wave_filters(w) for w in wn]
+    L = max(len(f[0]) for f in filt)
+    c = rng.standard_normal((n1, n2, n_in, 8))
+    pad = L - 1
+    cp = np.zeros((n1, n2, n_in + 2 * pad, 8))
+    cp[:, :, pad:pad + n_in] = c
+    ftz = [filt[0], filt[1], (np.pad(filt[2][0], ((L - len(filt[2][0])) // 2,) * 2), np.pad(filt[2][1], ((L - len(filt[2][1])) // 2,) * 2))]
+    full = orc.spatial_level_rec(cp, ftz, 1)                       # periodic, but the support never reaches the wrap
+    sa = L // 2 - 1
+    want = full[:, :, pad - sa:pad - sa + n_in + L - 1]            # planes [0, sa): owed to the slab before, the last L/2: to the one after
+    src = np.full((n1, n2, n_in + L - 1, 8), np.nan)
+    src[:, :, :n_in] = c
+    for variant in ((5, 8) if vec4 else (5,)):
+        got = _run(emu, src, wn, 1, True, np.float32, vec4, zchunk, small, z_wrap=3, variant=variant)
+        assert np.isfinite(got).all(), variant
+        assert np.abs(got - want).max() <= 2e-6 * max(np.abs(want).max(), 1.0), variant
+
+
 CASES_YC = [
     ((10, 9, 7), ("db1", "db3", "db1"), True, 0),
     ((12, 10, 9), ("db2", "db2", "db2"), False, 4),

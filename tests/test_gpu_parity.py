@@ -973,9 +973,10 @@ def _rccl_self_worker(rank, world, port, q):
             yref = w.dec(xs.permute(*reversed(range(d))), level).permute(*reversed(range(d + 1)))
             c = torch.randn_like(yref)
             want = w.rec(c.permute(*reversed(range(d + 1)))).permute(*reversed(range(d)))
-            for overlap in ((True, False) if d == 3 else (False,)):
+            for overlap, two in (((True, False), (True, True), (False, False)) if d == 3 else ((False, False),)):
                 try:
-                    eng = sh.ShardedNdDwt([wn] * d, sizes, pres_l2_norm=True, precision="single", device=dev, overlap=overlap, _self_p2p=True)
+                    eng = sh.ShardedNdDwt([wn] * d, sizes, pres_l2_norm=True, precision="single", device=dev, overlap=overlap,
+                                          two_streams=two, _self_p2p=True)
                     assert eng.scheme == "scatter" and not eng._host_stage and eng.world == 1
                     for rep in range(3):                            # later calls reuse the cached scratch / receive buffers
                         yl = eng.dec(xs, level)
@@ -995,7 +996,7 @@ def test_rccl_branch_of_the_sharded_driver_on_one_gpu():
     """the `nccl` branch of sharded.py executed for real: a 1-rank RCCL group, segments to self through P2POp"""
     (rank, errs, info), = _run_ranks(_rccl_self_worker, 1)
     assert not info, info
-    assert len(errs) == 15
+    assert len(errs) == 21
     for e_a, e_b in errs:
         assert e_a <= 4e-6 and e_b <= 2e-5, errs
 

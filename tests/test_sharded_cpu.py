@@ -129,9 +129,9 @@ def _worker(rank, world, port, sizes, wname, level, l2, dilation, scheme, q):
                                   engine=OracleSlabEngine(wname, l2), synthesis_scheme=scheme)
             assert eng.overlap_mode == "auto" and eng.overlap and eng.tuned is None
             rec = eng.tune(xk[eng.z0:eng.z1].contiguous(), level, steps=1)
-            assert rec["overlap"] == eng.overlap and rec["ms_overlap"] > 0 and rec["ms_one_piece"] > 0
+            assert (rec["schedule"] == "overlap") == eng.overlap and rec["ms_overlap"] > 0 and rec["ms_one_piece"] > 0
             votes = [None] * world
-            dist.all_gather_object(votes, (rec["overlap"], rec["ms_overlap"], rec["ms_one_piece"]))
+            dist.all_gather_object(votes, (rec["schedule"], rec["ms_overlap"], rec["ms_one_piece"]))
             assert len(set(votes)) == 1, votes                 # one decision from one set of numbers
             y_loc = eng.dec(xk[eng.z0:eng.z1].contiguous(), level)
             e_dec = max(e_dec, float(np.abs(y_loc.numpy() - want[:, eng.z0:eng.z1]).max()))

@@ -33,11 +33,11 @@ def timed(eng, steps=200):
     return (time.perf_counter() - t0) / steps * 1e3, r
 
 
-for overlap in (False, True):
-    eng = sh.ShardedNdDwt([wname] * 3, [512, 512, nloc], pres_l2_norm=True, precision="single", device=dev, overlap=overlap)
+for overlap, ts in ((False, False), (True, False), (True, True)):
+    eng = sh.ShardedNdDwt([wname] * 3, [512, 512, nloc], pres_l2_norm=True, precision="single", device=dev, overlap=overlap, two_streams=ts)
     ms, r = timed(eng)
     err = float((r - x).norm() / x.norm())
-    print(f"{wname} L{level} 512x512x{nloc} overlap={overlap}: {ms:.4f} ms per dec+rec (round trip {err:.2e})")
+    print(f"{wname} L{level} 512x512x{nloc} overlap={overlap} two_streams={ts}: {ms:.4f} ms per dec+rec (round trip {err:.2e})")
     # per-call events of one step
     e = eng.engine
     log = []
