@@ -765,9 +765,90 @@ static int synthesis_level(ndwt_plan* p, const T* const* in, T* out, long long s
 // 2^d-1 detail bands at [1 + (2^d-1)(level-lev), ...); the coarsest approximation is band 0.  Unlike
 // the reference there is no cat() copy (nd_dwt_3D.m:184) and no in-place overwrite of the input.
 // bs: distance between consecutive bands of y in scalars (p->vol = the packed reference layout; larger = pitched)
+// ---- two or three analysis levels of an image in one launch (Fwd2C, ndwt_device.h): float real data at tap stride 1, rows of whole
+// groups of 4 scalars, up to 8 taps or 12.  variant_fwd 9 keeps one launch per level (A/B); force_zchunk = rows per wave.
+static bool cascade2_eligible(const ndwt_plan* p, int* Lp_out) {
+    int Lp = 0;
+    if (p->dtype != NDWT_F32 || p->complexity != NDWT_REAL || p->dilation != NDWT_DILATION_REFERENCE || p->variant_fwd == 9) return false;
+    if (!fused2_eligible(p, 1, &Lp) || (Lp > 8 && Lp != 12) || p->dims[0] % 4 != 0) return false;
+    if (p->dims[0] * p->dims[1] >= (1LL << 31)) return false;   // the kernel's row * row-stride products are formed in 64 bits, offsets in int
+    *Lp_out = Lp;
+    return true;
+}
+
+static int cascade2_run(ndwt_plan* p, int Lp, int nlev, const float* in, float* const* out, hipStream_t s) {
+    Fused2CArgs<float> a;
+    memset(&a, 0, sizeof a);
+    a.in = in;
+    a.n1 = (int)p->dims[0];
+    a.n2 = (int)p->dims[1];
+    a.rs = a.n1;
+    bool aligned = aligned_vec4<float>(in);
+    for (int b = 0; b < 1 + 3 * nlev; ++b) { a.out[b] = out[b]; aligned = aligned && aligned_vec4<float>(out[b]); }
+    if (!aligned) return -1;
+    const int WX = fwd2c_tile_width(Lp, nlev);
+    a.ntx = (a.n1 + WX - 1) / WX;
+    // rows per wave: a wave reads nlev (Lp - 1) rows before its chunk produces anything, so chunks are longer than those of the
+    // one-level kernel; one round of `waves` waves (2 per SIMD at the 256-register budget)
+    // (db4, 3 levels, us per dec, one launch per level -> cascaded with 1024 / 2048 / 3584 waves: 4096^2 267 -> 206 / 179 / 190,
+    // 8192^2 1062 -> 692 / 586 / 636; 2048^2 52 -> 52, 1024^2 25 -> 45: the cascade serves images beyond 2048^2, tools/bench2d_cascade.py)
+    const int waves = p->target_blocks > 0 ? p->target_blocks : p->num_cus * 8;
+    int chunks = waves / a.ntx;
+    if (chunks < 1) chunks = 1;
+    int yc = (a.n2 + chunks - 1) / chunks;
+    const int min_chunk = nlev * (Lp - 1);                // the march-in is at most half of a wave's steps
+    if (yc < min_chunk) yc = min_chunk;
+    if (p->force_zchunk > 0) yc = p->force_zchunk;
+    if (yc > a.n2) yc = a.n2;
+    a.nyc = (a.n2 + yc - 1) / yc;
+    a.ychunk = (a.n2 + a.nyc - 1) / a.nyc;
+    a.nyc = (a.n2 + a.ychunk - 1) / a.ychunk;
+    a.nt = nt_store_ok<float>(a.rs, a.rs, 0, out, 1 + 3 * nlev);
+    a.mode = p->variant_fwd == 10 ? 1 : 0;
+    const void* td = p->taps_dev[0];
+    if (!td) return fail(NDWT_ERR_UNSUPPORTED, "plan has no device tap table");
+    prof_begin(p, NDWT_KERNEL_FUSED_ANALYSIS, s);
+    const int rc = launch_fwd2c_f32(a, Lp, nlev, td, s);
+    prof_end(p, s, rc);
+    if (rc == -2) return fail(NDWT_ERR_UNSUPPORTED, "internal: launch geometry does not match the cascaded 2-D kernel's tile");
+    if (rc > 0) return fail(NDWT_ERR_HIP, "cascaded 2-D analysis launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return rc;                                            // 0, or -1: no instance / unaligned (the caller takes one launch per level)
+}
+
 template <typename T> static int dec_impl(ndwt_plan* p, const T* x, T* y, long long bs, int level, hipStream_t s) {
     const int nb = 1 << p->ndim;
     const T* cur = x;
+    if constexpr (sizeof(T) == 4) {
+        int Lp = 0;
+        // images beyond 2048^2 (below, the rows a wave reads before its chunk produces anything outweigh the volumes saved), or on request
+        // (variant_fwd 11: tests and A/B runs on small images)
+        if (level >= 2 && p->ndim == 2 && cascade2_eligible(p, &Lp) && p->dims[1] >= 3 * (Lp - 1) &&
+            (p->vol > (6LL << 20) || p->variant_fwd == 11 || p->variant_fwd == 10)) {
+            int lev = 1;
+            while (level - lev + 1 >= 2) {                // levels lev .. lev + n - 1 in one launch
+                const int n = (level - lev + 1 >= 3 && Lp <= 8) ? 3 : 2;   // (12 taps: two levels fit the 256 registers, three do not)
+                const int last = lev + n - 1;
+                float* out[10];
+                out[0] = (last == level) ? y : (float*)p->approx[(last - 1) & 1];
+                for (int l = 0; l < n; ++l)               // cascade level l (0 = first) is transform level lev + l
+                    for (int b = 1; b < nb; ++b) out[1 + 3 * (n - 1 - l) + (b - 1)] = y + (long long)(1 + (nb - 1) * (level - (lev + l)) + (b - 1)) * bs;
+                const int rc = cascade2_run(p, Lp, n, cur, out, s);
+                if (rc == -1) break;                      // not this data (alignment): one launch per level from here on
+                if (rc) return rc;
+                cur = out[0];
+                lev = last + 1;
+            }
+            for (; lev <= level; ++lev) {
+                T* out[16];
+                out[0] = (lev == level) ? y : (T*)p->approx[(lev - 1) & 1];
+                for (int b = 1; b < nb; ++b) out[b] = y + (long long)(1 + (nb - 1) * (level - lev) + (b - 1)) * bs;
+                int rc = analysis_level<T>(p, cur, out, level_stride(p, lev), false, s);
+                if (rc) return rc;
+                cur = out[0];
+            }
+            return NDWT_OK;
+        }
+    }
     for (int lev = 1; lev <= level; ++lev) {
         T* out[16];
         out[0] = (lev == level) ? y : (T*)p->approx[(lev - 1) & 1];

@@ -2291,6 +2291,156 @@ template <typename T, int L_, bool VEC4_, int WPE_ = 4, int EW_ = 1> struct Fwd2
     }
 };
 
+// ---- NLEV analysis levels of an image in ONE launch (the reference's level loop, nd_dwt_2D.m:141-197, cascaded inside the march) ----
+// The reference applies the same un-dilated filters at every level, so level l + 1 is the same one-level analysis applied to the
+// approximation of level l.  A wave marches down its chunk of rows once: the raw row it reads enters the y window of level 1, the
+// approximation row level 1 completes enters the y window of level 2 in the same step, and so on -- the approximations between the
+// levels live in registers only (a per-level launch writes each to memory and the next launch reads it back: 1 + 3 NLEV + 1 volumes
+// move instead of 5 NLEV).  Level l runs l RH rows behind the raw row and is valid l GL / l GR lanes inside the wave, so a wave stores
+// 4 (64 - NLEV (GL + GR)) columns of every band and starts NLEV (L/2 - 1) rows above its chunk.  Same FMAs in the same order as NLEV
+// launches of Fwd2S.  Float / double real data, rows of whole groups of 4 scalars, periodic in y.
+template <typename T> struct Fused2CArgs {
+    const T* in;           // the image (or the approximation the cascade starts from)
+    T* out[10];            // [0] the approximation of the LAST level of the cascade; level l = 1 .. NLEV (1 = first / finest of the launch):
+                           // its detail bands b = 1 .. 3 at [1 + 3 (NLEV - l) + (b - 1)] -- the reference's band order for NLEV levels
+    int n1, n2;
+    int ychunk, ntx, nyc;
+    int rs;                // elements between rows
+    int nt;                // nontemporal stores
+    int mode;              // A/B (tools/bench2d_cascade.py): bit 0 = every level computes from its first input row on (no take-in-only steps)
+};
+
+template <typename T, int L_, int NLEV_, int WPE_ = 2> struct Fwd2C {
+    static constexpr int L = L_, NLEV = NLEV_, NT = 64, WPE = WPE_;
+    static constexpr int LH = L / 2 - 1, RH = L / 2;
+    static constexpr int GL = (LH + 3) / 4, GR = (RH + 3) / 4;
+    // output columns per wave: the lanes whose values are valid at every level, rounded down to whole 128-byte lines (8 lanes) so that no
+    // line of any band is shared by two waves (a partly written line of a nontemporal stream is a read-modify-write in memory)
+    static constexpr int WX = 4 * ((64 - NLEV * (GL + GR)) / 8 * 8);
+    static constexpr int XV = 4 * (1 + GL + GR);
+    static_assert(NLEV >= 2 && NLEV <= 3 && WX > 0, "two or three levels per launch");
+    typedef typename VecT<T>::v2 v2;
+    typedef typename VecT<T>::v4 v4;
+    typedef Taps3<T, L> Taps;                            // axes 0 (x) and 1 (y) are used
+    typedef Fused2CArgs<T> Args;
+    struct Shared { int unused; };
+    struct State {
+        v4 win[NLEV][L];   // the last L input rows of every level, rotating
+        v4 nxt;            // prefetched raw row
+        v4 cur;            // the row entering the level being processed (raw row, then the approximation rows)
+        v2 yz[4];          // (lo2, hi2) of this lane's 4 x, read by the neighbouring lanes
+        int off;
+    };
+
+    static NDWT_DEV void load_row(State& st, const Args& a, int yraw) {
+        st.nxt = *reinterpret_cast<const v4*>(a.in + (long long)modn(yraw, a.n2) * a.rs + st.off);
+    }
+    template <int LEV, int R> static NDWT_DEV void ystage(State& st, const Taps& tp) {
+        st.win[LEV][(R + L - 1) % L] = st.cur;
+        v2 acc[4];
+        acc[0] = acc[1] = acc[2] = acc[3] = (v2)(T(0));
+        NDWT_SFOR(j, L)
+            v4 w = st.win[LEV][(R + j) % L];
+            v2 t = {tp.lo[1][j], tp.hi[1][j]};
+            acc[0] += t * w[0]; acc[1] += t * w[1]; acc[2] += t * w[2]; acc[3] += t * w[3];
+        NDWT_SEND
+        st.yz[0] = acc[0]; st.yz[1] = acc[1]; st.yz[2] = acc[2]; st.yz[3] = acc[3];
+    }
+    // x filter of level LEV (every lane executes the shifts), stores of its bands for output row y if `emit`; its approximation row -> st.cur
+    template <int LEV, class Exec> static NDWT_DEV void xstage(Exec& ex, State& st, const Taps& tp, const Args& a, int x0, int y, bool emit,
+                                                               int tid) {
+        v2 xlo[4], xhi[4];
+        NDWT_SFOR(e, 4)
+            xlo[e] = (v2)(T(0));
+            xhi[e] = (v2)(T(0));
+        NDWT_SEND
+        NDWT_SFOR(i, XV)
+            constexpr int D = i / 4 - GL;
+            constexpr int c = i % 4;
+            {
+                v2 v = {NDWT_LANE_SHIFT(ex, tid, D, s.yz[c].x), NDWT_LANE_SHIFT(ex, tid, D, s.yz[c].y)};
+                NDWT_SFOR(e, 4)
+                    constexpr int j = i - 4 * GL - e + LH;
+                    if constexpr (j >= 0 && j < L) {
+                        xlo[e] += tp.lo[0][j] * v;
+                        xhi[e] += tp.hi[0][j] * v;
+                    }
+                NDWT_SEND
+            }
+        NDWT_SEND
+        const v4 o0 = {xlo[0].x, xlo[1].x, xlo[2].x, xlo[3].x}, o1 = {xhi[0].x, xhi[1].x, xhi[2].x, xhi[3].x};
+        const v4 o2 = {xlo[0].y, xlo[1].y, xlo[2].y, xlo[3].y}, o3 = {xhi[0].y, xhi[1].y, xhi[2].y, xhi[3].y};
+        st.cur = o0;
+        const int gx = x0 + 4 * (tid - NLEV * GL);
+        if (!emit || tid < NLEV * GL || tid >= NLEV * GL + WX / 4 || gx >= a.n1) return;
+        const long long off = (long long)y * a.rs + gx;
+        constexpr int d0 = 1 + 3 * (NLEV - 1 - LEV);      // LEV counts from 0 here
+        if constexpr (LEV == NLEV - 1) stream_store(reinterpret_cast<v4*>(a.out[0] + off), o0, a.nt);
+        stream_store(reinterpret_cast<v4*>(a.out[d0] + off), o1, a.nt);
+        stream_store(reinterpret_cast<v4*>(a.out[d0 + 1] + off), o2, a.nt);
+        stream_store(reinterpret_cast<v4*>(a.out[d0 + 2] + off), o3, a.nt);
+    }
+    // one step of the march with rotation R: raw row r has arrived; level LEV completes its output row r - (LEV + 1) RH
+    template <int R, class Exec> static NDWT_DEV void step(Exec& ex, const Args& a, const Taps& tp, int x0, int ybeg, int yend, int r, bool more) {
+        ex.each([&](int, State& st) __attribute__((always_inline)) {
+            st.cur = st.nxt;
+            if (more) load_row(st, a, r + 1);             // prefetch for the next step
+        });
+        const int s = r - (ybeg - NLEV * LH);             // step of the march
+        NDWT_SFOR(lev, NLEV)
+            // Level lev's input rows are valid from step lev (L - 1) on and its window is full L - 1 steps later: before the first it
+            // has nothing to do, between the two it only takes the row in (what it would compute is march-in garbage; wave-uniform tests)
+            if (lev == 0 || s >= (lev + 1) * (L - 1) || ((a.mode & 1) && s >= lev * (L - 1))) {
+                ex.each([&](int, State& st) __attribute__((always_inline)) { ystage<lev, R>(st, tp); });
+                const int y = r - (lev + 1) * RH;
+                const bool emit = y >= ybeg && y < yend;
+                ex.each([&](int tid, State& st) __attribute__((always_inline)) { xstage<lev>(ex, st, tp, a, x0, y, emit, tid); });
+            } else if (s >= lev * (L - 1)) {
+                ex.each([&](int, State& st) __attribute__((always_inline)) { st.win[lev][(R + L - 1) % L] = st.cur; });
+            }
+        NDWT_SEND
+    }
+    template <int R, class Exec> static NDWT_DEV void dispatch(int rot, Exec& ex, const Args& a, const Taps& tp, int x0, int ybeg, int yend, int r,
+                                                               bool more) {
+        if constexpr (R < L) {
+            if (rot == R) step<R>(ex, a, tp, x0, ybeg, yend, r, more);
+            else dispatch<R + 1>(rot, ex, a, tp, x0, ybeg, yend, r, more);
+        }
+    }
+
+    template <class Exec> static NDWT_DEV void block(Exec& ex, Shared&, const Args& a, const Taps& tp, int bid) {
+        const int tx = bid % a.ntx, yc = bid / a.ntx;
+        const int x0 = tx * WX;
+        const int ybeg = yc * a.ychunk;
+        const int yend = ybeg + a.ychunk < a.n2 ? ybeg + a.ychunk : a.n2;
+        const int r0 = ybeg - NLEV * LH;                  // first raw row: level NLEV's first output row needs it
+        ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+            st.off = modn(x0 - 4 * NLEV * GL + 4 * tid, a.n1);
+            NDWT_SFOR(lev, NLEV)
+                NDWT_SFOR(j, L)
+                    st.win[lev][j] = (v4)(T(0));
+                NDWT_SEND
+            NDWT_SEND
+            if (!(a.mode & 1)) {
+                NDWT_SFOR(j, L - 1)                      // steps 0 .. L-2: level 0 only takes rows in -- all of them in flight at once
+                    load_row(st, a, r0 + j);
+                    st.win[0][j] = st.nxt;
+                NDWT_SEND
+                load_row(st, a, r0 + L - 1);
+            } else {
+                load_row(st, a, r0);
+            }
+        });
+        const int nsteps = (yend - ybeg) + NLEV * (L - 1);
+        // step s >= L-1 runs with rotation (s + 1) % L: its row lands in slot L-1 at s = L-1, behind the rows of the steps before it
+        if (!(a.mode & 1)) {
+            for (int s = L - 1; s < nsteps; ++s) dispatch<0>((s + 1) % L, ex, a, tp, x0, ybeg, yend, r0 + s, s + 1 < nsteps);
+        } else {
+            for (int s = 0; s < nsteps; ++s) dispatch<0>(s % L, ex, a, tp, x0, ybeg, yend, r0 + s, s + 1 < nsteps);
+        }
+    }
+};
+
 template <typename T, int L_, bool VEC4_, int WPE_ = 4, int EW_ = 1> struct Inv2S {
     static constexpr int L = L_, NT = 64, WPE = WPE_, EW = EW_;
     static constexpr bool VEC4 = VEC4_;

@@ -52,6 +52,9 @@ int launch_inv2_f32_14to20(const Fused2Args<float>& a, int Lp, bool vec4, const 
 int launch_fwd2_c64_10to16(const Fused2Args<float>& a, int Lp, bool vec4, const void* taps_dev, hipStream_t s);    // interleaved complex64, db5 .. db8
 int launch_inv2_c64_10to16(const Fused2Args<float>& a, int Lp, bool vec4, const void* taps_dev, hipStream_t s);
 int launch_long2_f64(bool inverse, const Fused2Args<double>& a, int Lp, bool vec4, const void* taps_dev, hipStream_t s);   // double real, db7 / db8   // Inv2P: 2 or 4 rows in flight per wave
+// two or three analysis levels of an image in one launch (Fwd2C; float real data, rows of whole groups of 4, 2 .. 8 and 12 taps)
+int fwd2c_tile_width(int Lp, int nlev);
+int launch_fwd2c_f32(const Fused2CArgs<float>& a, int Lp, int nlev, const void* taps_dev, hipStream_t s);
 int launch_fwd2_f64(const Fused2Args<double>& a, int Lp, bool vec4, int ew, const void* taps_dev, hipStream_t s);
 int launch_inv2_f64(const Fused2Args<double>& a, int Lp, bool vec4, int ew, const void* taps_dev, hipStream_t s);
 

@@ -632,6 +632,27 @@ extern "C" int ndwt_emu_pin3_f32(int Lp, const float* x, float* out, int n1, int
 }
 #endif
 
+#if EMU_IN(16)
+// cascaded 2-D analysis (Fwd2C): out = 1 + 3 nlev bands in the reference's order for an nlev-level transform
+template <int LL, int NLEV> static int run_fwd2c(ndwt::Fused2CArgs<float>& a, const double* lo, const double* hi, int ychunk) {
+    typedef ndwt::Fwd2C<float, LL, NLEV, 2> K;
+    a.ntx = (a.n1 + K::WX - 1) / K::WX;
+    a.ychunk = ychunk > 0 ? (ychunk < a.n2 ? ychunk : a.n2) : a.n2;
+    a.nyc = (a.n2 + a.ychunk - 1) / a.ychunk;
+    typename K::Taps tp;
+    for (int ax = 0; ax < 3; ++ax)
+        for (int j = 0; j < LL; ++j) {
+            tp.lo[ax][j] = (float)lo[ax * ndwt::kMaxTaps + j];
+            tp.hi[ax][j] = (float)hi[ax * ndwt::kMaxTaps + j];
+        }
+    for (int b = 0; b < a.ntx * a.nyc; ++b) {
+        typename K::Shared sh;
+        EmuExec<typename K::State, K::NT> ex;
+        K::block(ex, sh, a, tp, b);
+    }
+    return 0;
+}
+#endif
 extern "C" {
 #if EMU_IN(1)
 int ndwt_emu_axisx_f32(int syn, int L, int ew, int vec4, const float* in0, const float* in1, float* out0, float* out1, long long row,
@@ -657,6 +678,22 @@ int ndwt_emu_march_f64(int syn, int L, const double* in0, const double* in1, dou
 int ndwt_emu2_f32(int inverse, int Lp, int vec4, const float* in, float* out, int n1, int n2, int ychunk, const double* lo,
                   const double* hi, int y_wrap, int ew, double shrink_thr, int shrink_mask, int shrink_hard, int dil) {
     return emu2<float>(inverse, Lp, vec4, in, out, n1, n2, ychunk, lo, hi, y_wrap, ew, shrink_thr, shrink_mask, shrink_hard, dil);
+}
+#endif
+#if EMU_IN(16)
+int ndwt_emu2_cascade_f32(int Lp, int nlev, const float* in, float* out, int n1, int n2, int ychunk, const double* lo, const double* hi) {
+    ndwt::Fused2CArgs<float> a;
+    std::memset(&a, 0, sizeof(a));
+    a.in = in; a.n1 = n1; a.n2 = n2; a.rs = n1;
+    for (int b = 0; b < 1 + 3 * nlev; ++b) a.out[b] = out + (long long)b * n1 * n2;
+#define CASEC(LL) case LL: return nlev == 3 ? run_fwd2c<LL, 3>(a, lo, hi, ychunk) : run_fwd2c<LL, 2>(a, lo, hi, ychunk);
+    if (nlev != 2 && nlev != 3) return -1;
+    switch (Lp) {
+        CASEC(2) CASEC(4) CASEC(6) CASEC(8)
+        case 12: return nlev == 2 ? run_fwd2c<12, 2>(a, lo, hi, ychunk) : -1;
+        default: return -1;
+    }
+#undef CASEC
 }
 #endif
 #if EMU_IN(4)

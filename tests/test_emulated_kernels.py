@@ -204,6 +204,40 @@ def test_emulated_pair_packed_synthesis_complex(emu, sizes, wn, vec4, zchunk, l2
         assert np.abs(got - want).max() <= 2e-6 * max(np.abs(want).max(), 1.0), variant
 
 
+@pytest.mark.slow
+@pytest.mark.parametrize("sizes,wn,nlev,ychunk", [
+    ((64, 40), ("db4", "db4"), 3, 0),            # one wave, one chunk
+    ((64, 57), ("db4", "db4"), 3, 13),           # chunks shorter than the march-in (21 rows): every level starts in another chunk's rows
+    ((260, 31), ("db2", "db3"), 2, 8),           # two waves along x (the second mostly outside the image), mixed wavelets
+    ((244, 26), ("db4", "db1"), 3, 0),           # 232 columns per wave with 8 taps: a 12-column second tile
+    ((64, 45), ("db6", "db6"), 2, 20),           # 12 taps: halo of two lanes per level on the right
+    ((32, 30), ("db1", "db1"), 3, 7),
+])
+@pytest.mark.parametrize("l2", [0, 1])
+def test_emulated_cascaded_2d_analysis(emu, sizes, wn, nlev, ychunk, l2):
+    """Fwd2C: two or three levels of an image in one march (the approximations between the levels never leave the registers) -- the
+    same bands as `nlev` levels of the oracle, in the reference's band order (nd_dwt_2D.m:141-197)"""
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal(sizes)
+    want = orc.spatial_dec(x, list(wn), nlev, l2)                          # (n1, n2, 1 + 3 nlev)
+    Lp = max(len(orc.wave_filters(w)[0]) for w in wn)
+    lo = np.zeros((3, 20))
+    hi = np.zeros((3, 20))
+    for ax in range(2):
+        t = kernel_taps(wn[ax], l2, Lp)
+        lo[ax, :Lp], hi[ax, :Lp] = t["ana_lo"], t["ana_hi"]
+    src = to_kernel_order(x).astype(np.float32)
+    n2, n1 = src.shape
+    out = np.full((1 + 3 * nlev, n2, n1), np.nan, dtype=np.float32)
+    emu.ndwt_emu2_cascade_f32.restype = ctypes.c_int
+    rc = emu.ndwt_emu2_cascade_f32(Lp, nlev, src.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), n1, n2, ychunk,
+                                   lo.ctypes.data_as(ctypes.c_void_p), hi.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0
+    got = np.transpose(out)
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+
+
 def _run2(emu, arr, wnames, l2, inverse, dtype, vec4, ychunk, cplx=False, shrink=(0.0, 0, 0), dil=1):
     Ls = [len(orc.wave_filters(w)[0]) for w in wnames]
     Lp = max(Ls)

@@ -746,6 +746,52 @@ def test_fused2d_kernels_at_baseline_config2_shape():
     assert float((y - yg).abs().max()) <= 2e-6 * float(yg.abs().max())
 
 
+@pytest.mark.parametrize("sizes,wn,level", [
+    ([256, 96], "db4", 3),                       # two waves along x (224 columns each), three levels in one launch
+    ([512, 130], ["db2", "db3"], 2),             # mixed wavelets padded to 6 taps, two levels
+    ([64, 200], "db6", 4),                       # 12 taps: two launches of two levels
+    ([1024, 64], "db1", 5),                      # 2 taps, five levels: a launch of three and one of two
+    ([260, 80], "db3", 4),                       # four levels: three in one launch, the fourth on the one-level kernel
+    ([232, 77], "db4", 3),
+])
+def test_cascaded_2d_analysis_against_oracle(sizes, wn, level):
+    """dec of a float image with the levels cascaded inside one march (Fwd2C; the default beyond 2048^2, forced here through
+    variant_fwd 11): the oracle's coefficients, bit-identical to one launch per level, and rec() inverts it"""
+    rng = np.random.default_rng(17)
+    x = rng.standard_normal(sizes)
+    wl = [wn] * 2 if isinstance(wn, str) else wn
+    want = orc.spatial_dec(x, wl, level, 1)
+    xg = _colmajor_gpu(x, "single")
+    res = {}
+    for variant in (11, 9):                      # cascaded / one launch per level
+        w = ndwt.nd_dwt_2D(wn, sizes, "pres_l2_norm", 1, "precision", "single")
+        w._plan(False, level, xg.device).set_variant(fwd=variant)
+        res[variant] = w.dec(xg, level)
+        assert _relerr(res[variant].cpu().numpy(), want) <= TOL["single"], variant
+    assert float((res[11] - res[9]).abs().max()) == 0.0
+    assert _relerr(w.rec(res[11]).cpu().numpy(), x) < 1e-5
+
+
+def test_cascaded_2d_analysis_is_the_default_at_cfg2_size():
+    """4096^2 db4, 3 levels (BASELINE config 2): one launch for the three levels (ndwt_plan_get_profile counts launches), same bits"""
+    torch.manual_seed(3)
+    n = 4096
+    x = torch.randn(n, n, device="cuda")
+    api = __import__("importlib").import_module("non-decimated_wavelets_amd.api")
+    nb = api.num_bands(2, 3)
+    s = torch.cuda.current_stream().cuda_stream
+    ys = []
+    for variant, launches in ((0, 1), (9, 3)):
+        p = api.Plan([n, n], ["db4"] * 2, torch.float32, False, True, "reference", max_level=3).set_variant(fwd=variant)
+        y = torch.empty((nb, n, n), device="cuda")
+        p.set_profiling(True)
+        p.dec(x.data_ptr(), y.data_ptr(), 3, s)
+        torch.cuda.synchronize()
+        assert p.get_profile(0)[1] == launches
+        ys.append(y)
+    assert float((ys[0] - ys[1]).abs().max()) == 0.0
+
+
 def _two_rank_worker(rank, world, port, q):
     """one of `world` processes that share cuda:0; slabs are exchanged over gloo (host staged)"""
     import importlib
