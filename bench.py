@@ -163,8 +163,15 @@ def measure_config(api, torch, dev, d, sizes, wname, level, steps, warmup):
     for k, (tot, n) in prof.items():
         if n:
             avg = tot / n
-            kern[KERNEL_NAMES[k]] = {"avg_launch_ms": round(avg, 4), "launches_per_step": n // psteps,
-                                     "frac": round(per_voxel[k] * V * 4 / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            lps = n // psteps
+            row = {"avg_launch_ms": round(avg, 4), "launches_per_step": lps}
+            if k in (0, 1) and lps and lps < level * (2 if d == 4 else 1):
+                # levels cascaded inside one launch (2-D): the launches of this direction together move the algorithmic bytes of `level` levels
+                row["levels_per_launch"] = round(level / lps, 2)
+                row["frac"] = round(level * per_voxel[k] * V * 4 / (avg * lps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            else:
+                row["frac"] = round(per_voxel[k] * V * 4 / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            kern[KERNEL_NAMES[k]] = row
     shape = "x".join(str(n) for n in sizes)
     out = {"workload": f"{d}D fp32 {shape} {wname} {level} levels, dec+rec, packed (reference) coefficients", "path": plan.describe(),
            "steps": steps, "ms_per_step": round(dt * 1e3, 4), "median_ms_per_step_hip_events": round(med, 4),

@@ -860,9 +860,79 @@ template <typename T> static int dec_impl(ndwt_plan* p, const T* x, T* y, long l
     return NDWT_OK;
 }
 
+// the synthesis side of the cascade (Inv2C): in[0] = approximation of the coarsest level, then the detail bands coarsest level first
+static int cascade2_rec_run(ndwt_plan* p, int Lp, int nlev, const float* const* in, float* out, hipStream_t s) {
+    Fused2CIArgs<float> a;
+    memset(&a, 0, sizeof a);
+    a.out = out;
+    a.n1 = (int)p->dims[0];
+    a.n2 = (int)p->dims[1];
+    a.rs = a.n1;
+    bool aligned = aligned_vec4<float>(out);
+    for (int b = 0; b < 1 + 3 * nlev; ++b) { a.in[b] = in[b]; aligned = aligned && aligned_vec4<float>(in[b]); }
+    if (!aligned) return -1;
+    const int WX = inv2c_tile_width(Lp, nlev);
+    a.ntx = (a.n1 + WX - 1) / WX;
+    // one wave per SIMD (db4, 3 levels, us per rec with 512 / 768 / 1024 / 1280 / 2048 waves: 4096^2 278 / 206 / 180 / 193 / 223 against 231
+    // for one launch per level, 8192^2 1003 / 708 / 607 / 637 / 707 against 936; two rows of band loads in flight per level: 177 / 608)
+    const int waves = p->target_blocks > 0 ? p->target_blocks : p->num_cus * 4;
+    int chunks = waves / a.ntx;
+    if (chunks < 1) chunks = 1;
+    int yc = (a.n2 + chunks - 1) / chunks;
+    const int min_chunk = nlev * (Lp - 1);
+    if (yc < min_chunk) yc = min_chunk;
+    if (p->force_zchunk > 0) yc = p->force_zchunk;
+    if (yc > a.n2) yc = a.n2;
+    a.nyc = (a.n2 + yc - 1) / yc;
+    a.ychunk = (a.n2 + a.nyc - 1) / a.nyc;
+    a.nyc = (a.n2 + a.ychunk - 1) / a.ychunk;
+    float* outs[1] = {out};
+    a.nt = nt_store_ok<float>(a.rs, a.rs, 0, outs, 1);
+    const void* td = p->taps_dev[1];
+    if (!td) return fail(NDWT_ERR_UNSUPPORTED, "plan has no device tap table");
+    prof_begin(p, NDWT_KERNEL_FUSED_SYNTHESIS, s);
+    const int rc = launch_inv2c_f32(a, Lp, nlev, p->variant_inv == 12 ? 2 : 1, td, s);
+    prof_end(p, s, rc);
+    if (rc == -2) return fail(NDWT_ERR_UNSUPPORTED, "internal: launch geometry does not match the cascaded 2-D kernel's tile");
+    if (rc > 0) return fail(NDWT_ERR_HIP, "cascaded 2-D synthesis launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return rc;
+}
+
 template <typename T> static int rec_impl(ndwt_plan* p, const T* y, long long bs, T* x, int level, hipStream_t s) {
     const int nb = 1 << p->ndim;
     const T* prev = y;   // band 0
+    if constexpr (sizeof(T) == 4) {
+        int Lp = 0;
+        // (variant_inv 9: one launch per level; 11: cascade whatever the image size; not while thresholding is fused into the loads)
+        if (level >= 2 && p->ndim == 2 && p->variant_inv != 9 && !p->shrink_mode && cascade2_eligible(p, &Lp) && Lp <= 8 &&
+            p->dims[1] >= 3 * (Lp - 1) && (p->vol > (6LL << 20) || p->variant_inv == 11 || p->variant_inv == 12)) {
+            int lev = level;                              // coarsest level still to be synthesised
+            while (lev >= 2) {
+                const int n = lev >= 3 ? 3 : 2;           // levels lev, lev - 1, .. lev - n + 1 in one launch
+                const float* in[10];
+                in[0] = prev;
+                for (int c = 0; c < n; ++c)               // cascade level c (0 = coarsest) is transform level lev - c
+                    for (int b = 1; b < nb; ++b) in[1 + 3 * c + (b - 1)] = y + (long long)(1 + (nb - 1) * (level - (lev - c)) + (b - 1)) * bs;
+                const int low = lev - n + 1;
+                float* dst = (low == 1) ? x : (float*)p->approx[(low - 1) & 1];
+                const int rc = cascade2_rec_run(p, Lp, n, in, dst, s);
+                if (rc == -1) break;
+                if (rc) return rc;
+                prev = dst;
+                lev = low - 1;
+            }
+            for (; lev >= 1; --lev) {
+                const T* in[16];
+                in[0] = prev;
+                for (int b = 1; b < nb; ++b) in[b] = y + (long long)(1 + (nb - 1) * (level - lev) + (b - 1)) * bs;
+                T* dst = (lev == 1) ? x : (T*)p->approx[(lev - 1) & 1];
+                int rc = synthesis_level<T>(p, in, dst, level_stride(p, lev), false, s);
+                if (rc) return rc;
+                prev = dst;
+            }
+            return NDWT_OK;
+        }
+    }
     for (int ind = 1; ind <= level; ++ind) {
         const int lev = level - ind + 1;
         const T* in[16];

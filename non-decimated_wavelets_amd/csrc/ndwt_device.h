@@ -2758,6 +2758,173 @@ template <typename T, int L_, int PD_ = 2, int WPE_ = 2, bool PK_ = false> struc
     }
 };
 
+// ---- NLEV synthesis levels of an image in ONE launch (the reference's level loop of rec, nd_dwt_2D.m:200-252, cascaded inside the march) ----
+// The mirror image of Fwd2C: a wave marches down its chunk once; the row the coarsest level of the cascade completes is, in the same
+// step, the approximation row of the level below it, whose detail rows are read next to it -- 1 + 3 NLEV volumes are read and one is
+// written (one launch per level reads 4 and writes 1 each).  Arithmetic of Inv2P's packed form (pairs of adjacent x outputs per
+// v_pk_fma_f32, tap pairs pinned in SGPRs), rows in groups of L so that rotations and load slots are compile-time constants; every level
+// computes in every step (what it makes of march-in rows never reaches an output row of the chunk), so the code is straight-line and the
+// compiler counts the loads in flight exactly.  Float real data, rows of whole groups of 4 scalars, periodic in y.
+template <typename T> struct Fused2CIArgs {
+    const T* in[10];       // [0] the approximation of the coarsest level; level l (1 = finest of the launch) detail bands b = 1 .. 3 at
+                           // [1 + 3 (NLEV - l) + (b - 1)] (the order of Fused2CArgs::out)
+    T* out;
+    int n1, n2;
+    int ychunk, ntx, nyc;
+    int rs;
+    int nt;
+};
+
+template <typename T, int L_, int NLEV_, int PD_ = 1, int WPE_ = 2> struct Inv2C {
+    static_assert(sizeof(T) == 4, "packed form: float only (v_pk_fma_f32)");
+    static constexpr int L = L_, NLEV = NLEV_, NT = 64, WPE = WPE_, PD = PD_;
+    static_assert(L % PD == 0 && NLEV >= 2 && NLEV <= 3, "the depth divides the tap length; two or three levels per launch");
+    static constexpr int LH = L / 2, RH = L / 2 - 1;
+    static constexpr int GL = (LH + 3) / 4, GR = (RH + 3) / 4;
+    static constexpr int WX = 4 * ((64 - NLEV * (GL + GR)) / 8 * 8);   // whole 128-byte lines per wave and row (see Fwd2C)
+    static constexpr int XV = 4 * (1 + GL + GR);
+    typedef typename VecT<T>::v4 v4;
+    typedef typename VecT<T>::v2 v2;
+    typedef Taps3Y<T, L> Taps;
+    typedef Fused2CIArgs<T> Args;
+    struct Shared { int unused; };
+    struct State {
+        T yacc[NLEV][L][4];          // per level: partial sums of its next L output rows (4 x each), rotating
+        v4 raw[NLEV][PD][4];         // rows in flight: level 0 (the coarsest) all 4 bands; finer levels [1 .. 3] = their detail bands
+        v4 cur[NLEV];                // cur[c]: the row level c - 1 has just completed = the approximation row of level c (c >= 1)
+        int off;
+    };
+    struct RegT {
+        v2 xl[L + 1], xh[L + 1];     // (t[k], t[k-1]) of the x low-pass / high-pass taps
+        v2 yl[L / 2], yh[L / 2];     // (t[2m], t[2m+1]) of the y taps
+    };
+    static NDWT_DEV void load_regt(RegT& rt, const Taps& tp) {
+        NDWT_SFOR(k, L + 1)
+            rt.xl[k] = PkF32::pinned(v2{tp.xplo[k][0], tp.xplo[k][1]});
+            rt.xh[k] = PkF32::pinned(v2{tp.xphi[k][0], tp.xphi[k][1]});
+        NDWT_SEND
+        NDWT_SFOR(m, L / 2)
+            rt.yl[m] = PkF32::pinned(v2{tp.lo[1][2 * m], tp.lo[1][2 * m + 1]});
+            rt.yh[m] = PkF32::pinned(v2{tp.hi[1][2 * m], tp.hi[1][2 * m + 1]});
+        NDWT_SEND
+    }
+    // band rows of level C (0 = coarsest) for march step p: level C consumes row rr0 + p - C RH (rows are periodic: any index loads)
+    template <int C, int S> static NDWT_DEV void load_rows(State& st, const Args& a, int row) {
+        const long long o = (long long)modn(row, a.n2) * a.rs + st.off;
+        if constexpr (C == 0) {
+            NDWT_SFOR(b, 4)
+                st.raw[0][S][b] = *reinterpret_cast<const v4*>(a.in[b] + o);
+            NDWT_SEND
+        } else {
+            NDWT_SFOR(b, 3)
+                st.raw[C][S][1 + b] = *reinterpret_cast<const v4*>(a.in[1 + 3 * C + b] + o);
+            NDWT_SEND
+        }
+    }
+    // level C of step K of a group (rotation R = (K + 1) % L, slot K % PD): x-synthesis via lane shifts, y-synthesis in scatter form;
+    // the row it completes -> cur[C + 1], or -- the finest level -- the output row y if `emit`
+    template <int C, int K, class Exec>
+    static NDWT_DEV void level(Exec& ex, State& st, const RegT& rt, const Args& a, int x0, int y, bool emit, int tid) {
+        constexpr int R = (K + 1) % L, S = K % PD;
+        v2 P[2][2];                                       // [y band][x outputs (0, 1) / (2, 3)]
+        P[0][0] = P[0][1] = P[1][0] = P[1][1] = (v2)(T(0));
+        NDWT_SFOR(ii, XV / 2)
+            constexpr int i0 = 2 * ii;
+            constexpr int D = i0 / 4 - GL;
+            constexpr int c = i0 % 4;
+            v2 w[4];
+            if constexpr (C == 0) w[0] = v2{NDWT_LANE_SHIFT(ex, tid, D, s.raw[0][S][0][c]), NDWT_LANE_SHIFT(ex, tid, D, s.raw[0][S][0][c + 1])};
+            else w[0] = v2{NDWT_LANE_SHIFT(ex, tid, D, s.cur[C][c]), NDWT_LANE_SHIFT(ex, tid, D, s.cur[C][c + 1])};
+            NDWT_SFOR(b, 3)
+                w[1 + b] = v2{NDWT_LANE_SHIFT(ex, tid, D, s.raw[C][S][1 + b][c]), NDWT_LANE_SHIFT(ex, tid, D, s.raw[C][S][1 + b][c + 1])};
+            NDWT_SEND
+            NDWT_SFOR(h, 2)
+                constexpr int k0 = i0 + h - 4 * GL + LH;
+                NDWT_SFOR(q, 2)
+                    constexpr int k = k0 - 2 * q;
+                    if constexpr (k >= 0 && k <= L) {
+                        PkF32::fma_bt<h, false, false, false>(P[0][q], w[0], rt.xl[k]);
+                        PkF32::fma_bt<h, false, false, false>(P[0][q], w[1], rt.xh[k]);
+                        PkF32::fma_bt<h, false, false, false>(P[1][q], w[2], rt.xl[k]);
+                        PkF32::fma_bt<h, false, false, false>(P[1][q], w[3], rt.xh[k]);
+                    }
+                NDWT_SEND
+            NDWT_SEND
+        NDWT_SEND
+        NDWT_SFOR(j, L)
+            constexpr int slot = ((R - 1 - j) % L + L) % L;
+            NDWT_SFOR(q, 2)
+                v2 acc;
+                if constexpr (j == 0) acc = (v2)(T(0));
+                else acc = v2{st.yacc[C][slot][2 * q], st.yacc[C][slot][2 * q + 1]};
+                PkF32::fma_s<j % 2, false>(acc, P[0][q], rt.yl[j / 2]);
+                PkF32::fma_s<j % 2, false>(acc, P[1][q], rt.yh[j / 2]);
+                st.yacc[C][slot][2 * q] = acc.x;
+                st.yacc[C][slot][2 * q + 1] = acc.y;
+            NDWT_SEND
+        NDWT_SEND
+        constexpr int done = ((R - L) % L + L) % L;
+        const v4 o = {st.yacc[C][done][0], st.yacc[C][done][1], st.yacc[C][done][2], st.yacc[C][done][3]};
+        if constexpr (C + 1 < NLEV) {
+            st.cur[C + 1] = o;
+        } else {
+            const int gx = x0 + 4 * (tid - NLEV * GL);
+            if (!emit || tid < NLEV * GL || tid >= NLEV * GL + WX / 4 || gx >= a.n1) return;
+            stream_store(reinterpret_cast<v4*>(a.out + (long long)y * a.rs + gx), o, a.nt);
+        }
+    }
+    // step p of the march (K = p % L): every level consumes its row, then the consumed load slots are refilled with the rows of step p + PD
+    template <int K, class Exec>
+    static NDWT_DEV void row(Exec& ex, const RegT& rt, const Args& a, int x0, int ybeg, int yend, int rr0, int p, int nrows) {
+        const int y = rr0 + p - NLEV * RH;
+        NDWT_SFOR(c, NLEV)
+            ex.each([&](int tid, State& st) __attribute__((always_inline)) { level<c, K>(ex, st, rt, a, x0, y, y >= ybeg && y < yend, tid); });
+        NDWT_SEND
+        ex.each([&](int, State& st) __attribute__((always_inline)) {
+            if (p + PD < nrows) {
+                NDWT_SFOR(c, NLEV)
+                    load_rows<c, K % PD>(st, a, rr0 + p + PD - c * RH);
+                NDWT_SEND
+            }
+        });
+    }
+    template <class Exec> static NDWT_DEV void block(Exec& ex, Shared&, const Args& a, const Taps& tp, int bid) {
+        const int tx = bid % a.ntx, yc = bid / a.ntx;
+        const int x0 = tx * WX;
+        const int ybeg = yc * a.ychunk;
+        const int yend = ybeg + a.ychunk < a.n2 ? ybeg + a.ychunk : a.n2;
+        const int rr0 = ybeg - NLEV * LH;                 // the coarsest level's first row: the chunk's first output row needs it
+        const int nrows = (yend - ybeg) + NLEV * (L - 1);
+        RegT rt;
+        load_regt(rt, tp);
+        ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+            st.off = modn(x0 - 4 * NLEV * GL + 4 * tid, a.n1);
+            NDWT_SFOR(c, NLEV)                            // (sums and rows of levels whose march-in has not reached them yet: finite values)
+                st.cur[c] = (v4)(T(0));
+                NDWT_SFOR(j, L)
+                    NDWT_SFOR(e, 4)
+                        st.yacc[c][j][e] = T(0);
+                    NDWT_SEND
+                NDWT_SEND
+            NDWT_SEND
+            NDWT_SFOR(q, PD)
+                NDWT_SFOR(c, NLEV)
+                    load_rows<c, q>(st, a, rr0 + q - c * RH);
+                NDWT_SEND
+            NDWT_SEND
+        });
+        int p = 0;
+        for (; p + L <= nrows; p += L) {                  // whole groups: straight-line code, no test per row
+            NDWT_SFOR(k, L)
+                row<k>(ex, rt, a, x0, ybeg, yend, rr0, p + k, nrows);
+            NDWT_SEND
+        }
+        NDWT_SFOR(k, L - 1)                               // the last, partial group
+            if (p + k < nrows) row<k>(ex, rt, a, x0, ybeg, yend, rr0, p + k, nrows);
+        NDWT_SEND
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // One non-contiguous axis per launch, marched with the filter window in registers (no LDS, no halo re-reads):
 // 1 read -> 2 writes (analysis) / 2 reads -> 1 write (synthesis, scatter form).  The array is [outer][N][inner];

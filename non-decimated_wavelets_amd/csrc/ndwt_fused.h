@@ -55,6 +55,9 @@ int launch_long2_f64(bool inverse, const Fused2Args<double>& a, int Lp, bool vec
 // two or three analysis levels of an image in one launch (Fwd2C; float real data, rows of whole groups of 4, 2 .. 8 and 12 taps)
 int fwd2c_tile_width(int Lp, int nlev);
 int launch_fwd2c_f32(const Fused2CArgs<float>& a, int Lp, int nlev, const void* taps_dev, hipStream_t s);
+// ... and the synthesis levels (Inv2C; 2 .. 8 taps; depth = rows of band loads in flight per level)
+int inv2c_tile_width(int Lp, int nlev);
+int launch_inv2c_f32(const Fused2CIArgs<float>& a, int Lp, int nlev, int depth, const void* taps_dev, hipStream_t s);
 int launch_fwd2_f64(const Fused2Args<double>& a, int Lp, bool vec4, int ew, const void* taps_dev, hipStream_t s);
 int launch_inv2_f64(const Fused2Args<double>& a, int Lp, bool vec4, int ew, const void* taps_dev, hipStream_t s);
 

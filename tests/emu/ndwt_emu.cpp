@@ -633,6 +633,26 @@ extern "C" int ndwt_emu_pin3_f32(int Lp, const float* x, float* out, int n1, int
 #endif
 
 #if EMU_IN(16)
+// cascaded 2-D synthesis (Inv2C): in = 1 + 3 nlev bands in the reference's order
+template <int LL, int NLEV, int PD> static int run_inv2c(ndwt::Fused2CIArgs<float>& a, const double* lo, const double* hi, int ychunk) {
+    typedef ndwt::Inv2C<float, LL, NLEV, PD, 2> K;
+    a.ntx = (a.n1 + K::WX - 1) / K::WX;
+    a.ychunk = ychunk > 0 ? (ychunk < a.n2 ? ychunk : a.n2) : a.n2;
+    a.nyc = (a.n2 + a.ychunk - 1) / a.ychunk;
+    typename K::Taps tp;
+    for (int ax = 0; ax < 3; ++ax)
+        for (int j = 0; j < LL; ++j) {
+            tp.lo[ax][j] = (float)lo[ax * ndwt::kMaxTaps + j];
+            tp.hi[ax][j] = (float)hi[ax * ndwt::kMaxTaps + j];
+        }
+    fill_x_pairs(tp, lo, hi, LL, 0);
+    for (int b = 0; b < a.ntx * a.nyc; ++b) {
+        typename K::Shared sh;
+        EmuExec<typename K::State, K::NT> ex;
+        K::block(ex, sh, a, tp, b);
+    }
+    return 0;
+}
 // cascaded 2-D analysis (Fwd2C): out = 1 + 3 nlev bands in the reference's order for an nlev-level transform
 template <int LL, int NLEV> static int run_fwd2c(ndwt::Fused2CArgs<float>& a, const double* lo, const double* hi, int ychunk) {
     typedef ndwt::Fwd2C<float, LL, NLEV, 2> K;
@@ -681,6 +701,20 @@ int ndwt_emu2_f32(int inverse, int Lp, int vec4, const float* in, float* out, in
 }
 #endif
 #if EMU_IN(16)
+int ndwt_emu2_cascade_inv_f32(int Lp, int nlev, int depth, const float* in, float* out, int n1, int n2, int ychunk, const double* lo, const double* hi) {
+    ndwt::Fused2CIArgs<float> a;
+    std::memset(&a, 0, sizeof(a));
+    a.out = out; a.n1 = n1; a.n2 = n2; a.rs = n1;
+    for (int b = 0; b < 1 + 3 * nlev; ++b) a.in[b] = in + (long long)b * n1 * n2;
+#define CASEC(LL) case LL: return nlev == 3 ? (depth == 2 ? run_inv2c<LL, 3, 2>(a, lo, hi, ychunk) : run_inv2c<LL, 3, 1>(a, lo, hi, ychunk)) \
+                                            : (depth == 2 ? run_inv2c<LL, 2, 2>(a, lo, hi, ychunk) : run_inv2c<LL, 2, 1>(a, lo, hi, ychunk));
+    if (nlev != 2 && nlev != 3) return -1;
+    switch (Lp) {
+        CASEC(2) CASEC(4) CASEC(6) CASEC(8)
+        default: return -1;
+    }
+#undef CASEC
+}
 int ndwt_emu2_cascade_f32(int Lp, int nlev, const float* in, float* out, int n1, int n2, int ychunk, const double* lo, const double* hi) {
     ndwt::Fused2CArgs<float> a;
     std::memset(&a, 0, sizeof(a));

@@ -238,6 +238,39 @@ def test_emulated_cascaded_2d_analysis(emu, sizes, wn, nlev, ychunk, l2):
     assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
 
 
+@pytest.mark.slow
+@pytest.mark.parametrize("sizes,wn,nlev,ychunk,depth", [
+    ((64, 40), ("db4", "db4"), 3, 0, 1),
+    ((64, 57), ("db4", "db4"), 3, 13, 2),        # chunks shorter than the march-in; two rows of band loads in flight
+    ((260, 31), ("db2", "db3"), 2, 8, 1),        # two waves along x, mixed wavelets
+    ((244, 26), ("db4", "db2"), 3, 0, 1),
+    ((64, 45), ("db3", "db3"), 2, 20, 2),
+    ((32, 30), ("db1", "db1"), 3, 7, 1),
+])
+@pytest.mark.parametrize("l2", [0, 1])
+def test_emulated_cascaded_2d_synthesis(emu, sizes, wn, nlev, ychunk, depth, l2):
+    """Inv2C: two or three synthesis levels of an image in one march -- rec of arbitrary coefficients as the oracle computes it"""
+    rng = np.random.default_rng(32)
+    c = rng.standard_normal(tuple(sizes) + (1 + 3 * nlev,))
+    want = orc.spatial_rec(c, list(wn), l2)
+    Lp = max(len(orc.wave_filters(w)[0]) for w in wn)
+    lo = np.zeros((3, 20))
+    hi = np.zeros((3, 20))
+    for ax in range(2):
+        t = kernel_taps(wn[ax], l2, Lp)
+        lo[ax, :Lp], hi[ax, :Lp] = t["syn_lo"], t["syn_hi"]
+    src = to_kernel_order(c).astype(np.float32)
+    n2, n1 = src.shape[1:]
+    out = np.full((n2, n1), np.nan, dtype=np.float32)
+    emu.ndwt_emu2_cascade_inv_f32.restype = ctypes.c_int
+    rc = emu.ndwt_emu2_cascade_inv_f32(Lp, nlev, depth, src.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), n1, n2, ychunk,
+                                       lo.ctypes.data_as(ctypes.c_void_p), hi.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0
+    got = np.transpose(out)
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= 4e-6 * max(np.abs(want).max(), 1.0)
+
+
 def _run2(emu, arr, wnames, l2, inverse, dtype, vec4, ychunk, cplx=False, shrink=(0.0, 0, 0), dil=1):
     Ls = [len(orc.wave_filters(w)[0]) for w in wnames]
     Lp = max(Ls)

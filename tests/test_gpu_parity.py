@@ -772,6 +772,33 @@ def test_cascaded_2d_analysis_against_oracle(sizes, wn, level):
     assert _relerr(w.rec(res[11]).cpu().numpy(), x) < 1e-5
 
 
+@pytest.mark.parametrize("sizes,wn,level,depth", [
+    ([256, 96], "db4", 3, 1),
+    ([512, 130], ["db2", "db3"], 2, 2),          # two rows of band loads in flight per level
+    ([1024, 64], "db1", 5, 1),                   # five levels: a launch of three and one of two
+    ([260, 80], "db3", 4, 1),                    # four levels: three in one launch, the finest on the one-level kernel
+    ([232, 77], "db4", 3, 2),
+])
+def test_cascaded_2d_synthesis_against_oracle(sizes, wn, level, depth):
+    """rec of arbitrary float coefficients with the levels cascaded inside one march (Inv2C; the default beyond 2048^2, forced here through
+    variant_inv 11 / 12): the oracle's reconstruction, and the same bits as one launch per level"""
+    rng = np.random.default_rng(18)
+    wl = [wn] * 2 if isinstance(wn, str) else wn
+    c = rng.standard_normal(sizes + [ndwt.num_bands(2, level)])
+    want = orc.spatial_rec(c, wl, 1)
+    cg = _colmajor_gpu(c, "single")
+    res = {}
+    for variant in (11 if depth == 1 else 12, 9):
+        w = ndwt.nd_dwt_2D(wn, sizes, "pres_l2_norm", 1, "precision", "single")
+        w._plan(False, level, cg.device).set_variant(inv=variant)
+        res[variant] = w.rec(cg)
+        assert np.abs(res[variant].cpu().numpy() - want).max() <= 2 * TOL["single"] * max(np.abs(want).max(), np.abs(c).max()), variant
+    a, b = list(res.values())
+    # (the one-level kernels run 4 / 8 / 12 taps as packed FMAs like the cascade -- the same bits -- and other tap lengths as scalar ones)
+    Lp = max(len(ndwt.wave_filters(v)[0]) for v in wl)
+    assert float((a - b).abs().max()) <= (0.0 if Lp in (4, 8) else 2 * TOL["single"] * float(b.abs().max()))
+
+
 def test_cascaded_2d_analysis_is_the_default_at_cfg2_size():
     """4096^2 db4, 3 levels (BASELINE config 2): one launch for the three levels (ndwt_plan_get_profile counts launches), same bits"""
     torch.manual_seed(3)
@@ -790,6 +817,17 @@ def test_cascaded_2d_analysis_is_the_default_at_cfg2_size():
         assert p.get_profile(0)[1] == launches
         ys.append(y)
     assert float((ys[0] - ys[1]).abs().max()) == 0.0
+    rs = []
+    for variant, launches in ((0, 1), (9, 3)):                # ... and the synthesis side
+        p = api.Plan([n, n], ["db4"] * 2, torch.float32, False, True, "reference", max_level=3).set_variant(inv=variant)
+        r = torch.empty(n, n, device="cuda")
+        p.set_profiling(True)
+        p.rec(ys[0].data_ptr(), r.data_ptr(), 3, s)
+        torch.cuda.synchronize()
+        assert p.get_profile(1)[1] == launches
+        rs.append(r)
+    assert float((rs[0] - rs[1]).abs().max()) == 0.0
+    assert float((rs[0] - x).norm() / x.norm()) < 1e-6
 
 
 def _two_rank_worker(rank, world, port, q):

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""cfg2 (4096^2 fp32, 3 levels): dec with the levels cascaded in one launch (Fwd2C) against one launch per level, interleaved A/B;
-rows per wave swept.   python tools/bench2d_cascade.py [wname] [n]"""
+"""cfg2 (4096^2 fp32, 3 levels): dec / rec with the levels cascaded in one launch (Fwd2C / Inv2C) against one launch per level; the
+variants interleaved in batches of 20 back-to-back calls.   python tools/bench2d_cascade.py [wname] [n]"""
 import importlib
 import os
+import statistics
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,37 +16,40 @@ level = 3
 x = torch.randn(n, n, device="cuda")
 nb = api.num_bands(2, level)
 s = torch.cuda.current_stream().cuda_stream
-ys = {}
-plans = {}
-pitches = {}
-for name, (var, chunk, tb, pitch) in {"per-level": (9, 0, 0, 0), "cascade": (0, 0, 0, 0), "cascade/w1024": (0, 0, 1024, 0), "cascade/w2048": (0, 0, 2048, 0), "cascade/w3584": (0, 0, 3584, 0),
-                               "cascade/24": (0, 24, 0, 0), "cascade/32": (0, 32, 0, 0), "cascade/44": (0, 44, 0, 0), "cascade/64": (0, 64, 0, 0), "cascade/96": (0, 96, 0, 0)}.items():
-    pitches[name] = (n * n + pitch) if pitch else 0
+y = torch.randn((nb, n, n), device="cuda")
+plans, outs = {}, {}
+# name: (variant_fwd, variant_inv, rows per wave, waves)
+for name, (vf, vi, chunk, tb) in {"per-level": (9, 9, 0, 0), "cascade/w2048": (11, 11, 0, 2048), "cascade/w512": (11, 11, 0, 512), "cascade/w768": (11, 11, 0, 768),
+                                   "cascade/w896": (11, 11, 0, 896), "cascade/w1024": (11, 11, 0, 1024), "cascade/w1152": (11, 11, 0, 1152), "cascade/w1280": (11, 11, 0, 1280),
+                                   "cascade/d2/w896": (11, 12, 0, 896), "cascade/d2/w1024": (11, 12, 0, 1024)}.items():
     p = api.Plan([n, n], [wname] * 2, torch.float32, False, True, "reference", max_level=level)
-    p.set_variant(fwd=var)
+    p.set_variant(fwd=vf, inv=vi)
     p.set_tuning(tb, chunk)
     plans[name] = p
-    ys[name] = torch.empty(nb * (n * n + 1024), device="cuda")
-    p.dec(x.data_ptr(), ys[name].data_ptr(), level, s, band_pitch=pitches[name])
+    outs[name] = (torch.empty((nb, n, n), device="cuda"), torch.empty(n, n, device="cuda"))
+    p.dec(x.data_ptr(), outs[name][0].data_ptr(), level, s)
+    p.rec(y.data_ptr(), outs[name][1].data_ptr(), level, s)
 torch.cuda.synchronize()
-ref = ys["per-level"]
-def bands(name):
-    pt = pitches[name] or n * n
-    return torch.stack([ys[name][b * pt:b * pt + n * n] for b in range(nb)])
 for name in plans:
-    print(f"{name:14s} max |diff to per-level| = {float((bands(name) - bands('per-level')).abs().max()):.3e}")
-import statistics
-res = {k: [] for k in plans}
-for r in range(6):                                        # batches of 20 back-to-back calls, the variants interleaved batch by batch
+    print(f"{name:18s} max |diff to per-level|: dec {float((outs[name][0] - outs['per-level'][0]).abs().max()):.2e}  "
+          f"rec {float((outs[name][1] - outs['per-level'][1]).abs().max()):.2e} (max |rec| {float(outs['per-level'][1].abs().max()):.1f})")
+res = {k: ([], []) for k in plans}
+for r in range(6):
     for name, p in plans.items():
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        p.dec(x.data_ptr(), ys[name].data_ptr(), level, s, band_pitch=pitches[name])
-        e0.record()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        p.dec(x.data_ptr(), outs[name][0].data_ptr(), level, s)
+        ev[0].record()
         for _ in range(20):
-            p.dec(x.data_ptr(), ys[name].data_ptr(), level, s, band_pitch=pitches[name])
-        e1.record()
+            p.dec(x.data_ptr(), outs[name][0].data_ptr(), level, s)
+        ev[1].record()
+        p.rec(y.data_ptr(), outs[name][1].data_ptr(), level, s)
+        ev[2].record()
+        for _ in range(20):
+            p.rec(y.data_ptr(), outs[name][1].data_ptr(), level, s)
+        ev[3].record()
         torch.cuda.synchronize()
         if r >= 1:
-            res[name].append(e0.elapsed_time(e1) / 20 * 1e3)
+            res[name][0].append(ev[0].elapsed_time(ev[1]) / 20 * 1e3)
+            res[name][1].append(ev[2].elapsed_time(ev[3]) / 20 * 1e3)
 for name in plans:
-    print(f"{name:14s} dec {wname} {n}^2 L{level}: median {statistics.median(res[name]):.1f} us  min {min(res[name]):.1f}  max {max(res[name]):.1f}")
+    print(f"{name:18s} {wname} {n}^2 L{level}: dec {statistics.median(res[name][0]):7.1f} us   rec {statistics.median(res[name][1]):7.1f} us")
