@@ -127,6 +127,30 @@ int64_t ndwt_band_pitch(const ndwt_plan* plan);   /* the recommended pitch in el
 int ndwt_dec_host(ndwt_plan* plan, const void* x_host, void* y_host, int level);
 int ndwt_rec_host(ndwt_plan* plan, const void* y_host, void* x_host, int level);
 
+/* Staging of the host-pointer forms is owned by the plan, grown on demand and kept across calls (a 512^3 3-level transform stages
+ * 12.3 GB: allocating and freeing it per call costs milliseconds, and the gateway is called thousands of times by an iterative
+ * solver, README.md:2).  ndwt_plan_release_staging gives the memory back (the next host-pointer call allocates again). */
+int ndwt_plan_release_staging(ndwt_plan* plan);
+
+/* ---- device-resident coefficients ------------------------------------------------------------------------
+ * The reference's gateway moves the whole coefficient array through host memory on every call (y = nd_dwt_mex(...) at
+ * nd_dwt_3D.m:161, x = nd_dwt_mex(y, ...) at :225): 11.8 GB per direction for a 512^3 3-level transform, 0.2 s over PCIe against
+ * 3 ms of compute.  A solver that only needs rec(shrink(dec(x))) -- or that keeps y between iterations -- can leave the coefficients
+ * on the device behind an opaque handle: only the signal crosses the link.  The handle is bound to the plan that made it (same
+ * dims / wavelets / precision); it owns a pitched coefficient array (ndwt_band_pitch) and must be released before its plan is
+ * destroyed.  All calls are synchronous on the null stream, like the other host-pointer forms. */
+typedef struct ndwt_coef ndwt_coef;
+int ndwt_coef_create(ndwt_plan* plan, int level, ndwt_coef** coef);                       /* uninitialised coefficients of `level` levels */
+int ndwt_coef_release(ndwt_coef* coef);
+int ndwt_coef_info(const ndwt_coef* coef, int* level, int64_t* bands, int64_t* band_pitch, void** dev_ptr);
+/* dec: x_host -> coefficients on the device.  *coef == NULL: a new handle is returned; else that handle (same plan and level) is refilled */
+int ndwt_coef_dec_host(ndwt_plan* plan, const void* x_host, int level, ndwt_coef** coef);
+int ndwt_coef_rec_host(ndwt_plan* plan, const ndwt_coef* coef, void* x_host);             /* rec: coefficients on the device -> x_host */
+int ndwt_coef_shrink(ndwt_plan* plan, ndwt_coef* coef, double threshold, int mode);       /* NDWT_SHRINK_* of the detail bands, in place */
+/* the whole array in the reference's packed layout [dims, bands] to / from host memory (for callers that do need y) */
+int ndwt_coef_get_host(ndwt_plan* plan, const ndwt_coef* coef, void* y_host);
+int ndwt_coef_put_host(ndwt_plan* plan, int level, const void* y_host, ndwt_coef** coef);
+
 /* ---- consumers for iterative solvers (extension; the reference's users threshold the bands in MATLAB, README.md:2) ----
  * ndwt_shrink: in-place soft / hard thresholding of every detail band of a level-`level` coefficient array (band 0, the
  *   coarsest approximation, is kept); complex data: the magnitude is shrunk, the phase kept.

@@ -16,6 +16,7 @@ classdef (Abstract) nd_dwt_hip_base
         precision = 'double';
         dilation = 'reference';     % 'atrous': textbook SWT (taps dilated by 2^(level-1)); the reference never dilates
         devices = [];               % HIP device ordinals: empty = device 0, one = that device, several = the outermost axis sharded over them (2-D .. 4-D)
+        exchange = 'scatter';       % several devices, rec: 'scatter' = one band of partial sums per level (equal to one device to rounding); 'gather' = bit-identical
     end
     methods (Abstract, Access = protected)
         d = ndim_(obj)                       % number of dimensions
@@ -43,6 +44,7 @@ classdef (Abstract) nd_dwt_hip_base
                     case 'precision',    obj.precision = varargin{ind+1};
                     case 'dilation',     obj.dilation = varargin{ind+1};
                     case 'devices',      obj.devices = double(varargin{ind+1}(:).');
+                    case 'exchange',     obj.exchange = varargin{ind+1};
                     otherwise, warning(sprintf('Unknown optional input #%d ingoring!', ind));
                 end
             end
@@ -61,12 +63,36 @@ classdef (Abstract) nd_dwt_hip_base
         function y = dec(obj, x, level)
             if obj.ndim_() == 1 && size(x, 1) == 1, x = x.'; end      % nd_dwt_1D.m:151-153
             if strcmpi(obj.precision, 'single'), x = single(x); else, x = double(x); end
-            y = nd_dwt_hip_mex(x, obj.wname(1:obj.ndim_()), 0, level, obj.pres_l2_norm, obj.dilation, obj.devices);
+            y = nd_dwt_hip_mex(x, obj.wname(1:obj.ndim_()), 0, level, obj.pres_l2_norm, obj.dilation, obj.devices, obj.exchange);
+        end
+        % ---- device-resident coefficients: only the signal crosses PCIe (the reference's dec / rec move the whole coefficient array) ----
+        function h = dec_keep(obj, x, level)
+            % dec(x, level) whose result stays on the device; returns a uint64 handle for rec_kept / shrink_kept / fetch / release
+            if obj.ndim_() == 1 && size(x, 1) == 1, x = x.'; end
+            if strcmpi(obj.precision, 'single'), x = single(x); else, x = double(x); end
+            h = nd_dwt_hip_mex('dec_keep', x, obj.wname(1:obj.ndim_()), level, obj.pres_l2_norm, obj.dilation, obj.device_());
+        end
+        function x = rec_kept(obj, h),            x = nd_dwt_hip_mex('rec_handle', h); end   %#ok<INUSL>
+        function shrink_kept(obj, h, thr, mode)   %#ok<INUSL>
+            if nargin < 4, mode = 'soft'; end
+            nd_dwt_hip_mex('shrink', h, thr, mode);
+        end
+        function y = fetch(obj, h),               y = nd_dwt_hip_mex('fetch', h); end        %#ok<INUSL>
+        function release(obj, h),                 nd_dwt_hip_mex('release', h); end          %#ok<INUSL>
+        function xd = denoise(obj, x, level, thr, mode)
+            % rec(shrink(dec(x, level), thr)) in one call; the coefficients never leave the device
+            if nargin < 5, mode = 'soft'; end
+            if obj.ndim_() == 1 && size(x, 1) == 1, x = x.'; end
+            if strcmpi(obj.precision, 'single'), x = single(x); else, x = double(x); end
+            xd = nd_dwt_hip_mex('denoise', x, obj.wname(1:obj.ndim_()), level, obj.pres_l2_norm, thr, mode, obj.dilation, obj.device_());
+        end
+        function dev = device_(obj)
+            if isempty(obj.devices), dev = 0; else, dev = obj.devices(1); end
         end
         function y = rec(obj, x)
             level = obj.level_from_bands_(size(x, obj.ndim_() + 1));
             if strcmpi(obj.precision, 'single'), x = single(x); else, x = double(x); end
-            y = nd_dwt_hip_mex(x, obj.wname(1:obj.ndim_()), 1, level, obj.pres_l2_norm, obj.dilation, obj.devices);
+            y = nd_dwt_hip_mex(x, obj.wname(1:obj.ndim_()), 1, level, obj.pres_l2_norm, obj.dilation, obj.devices, obj.exchange);
         end
     end
 end

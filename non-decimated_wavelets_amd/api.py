@@ -142,6 +142,9 @@ class Plan:
         L.check(L.lib().ndwt_slab_segments(self._h, 1 if add else 0, n, (ctypes.c_void_p * n)(*dsts), (ctypes.c_void_p * n)(*srcs),
                                            (ctypes.c_int64 * n)(*counts), ctypes.c_void_p(stream)))
 
+    def release_staging(self):
+        L.check(L.lib().ndwt_plan_release_staging(self._h))
+
     def slab_halo(self, stride=1):
         v = [ctypes.c_int64(0) for _ in range(4)]
         L.check(L.lib().ndwt_slab_halo(self._h, int(stride), *[ctypes.byref(t) for t in v]))
@@ -183,6 +186,59 @@ class Plan:
     def synthesis_level_slab(self, in_ptrs, out_ptr, stride=1, stream=0):
         arr = (ctypes.c_void_p * len(in_ptrs))(*in_ptrs)
         L.check(L.lib().ndwt_synthesis_level_slab(self._h, arr, out_ptr, int(stride), ctypes.c_void_p(stream)))
+
+
+class Coefficients:
+    """Device-resident coefficients behind an opaque handle (include/ndwt.h: ndwt_coef_*): what the MATLAB gateway's `dec_keep` /
+    `rec_handle` commands hold between calls -- only the signal crosses PCIe (the reference's gateway moves the whole coefficient
+    array through host memory per call, nd_dwt_3D.m:161,225).  Host arrays are numpy, kernel order ((bands,) nd, ..., n1)."""
+
+    def __init__(self, plan: Plan, handle: ctypes.c_void_p):
+        self.plan, self._h = plan, handle
+
+    @classmethod
+    def dec(cls, plan: Plan, x: np.ndarray, level: int, reuse: "Coefficients | None" = None):
+        h = reuse._h if reuse is not None else ctypes.c_void_p(None)
+        x = np.ascontiguousarray(x)
+        L.check(L.lib().ndwt_coef_dec_host(plan._h, x.ctypes.data_as(ctypes.c_void_p), int(level), ctypes.byref(h)))
+        return reuse if reuse is not None else cls(plan, h)
+
+    @classmethod
+    def put(cls, plan: Plan, y: np.ndarray, level: int):
+        h = ctypes.c_void_p(None)
+        y = np.ascontiguousarray(y)
+        L.check(L.lib().ndwt_coef_put_host(plan._h, int(level), y.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h)))
+        return cls(plan, h)
+
+    def info(self):
+        lev, nb, pitch, ptr = ctypes.c_int(0), ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_void_p(None)
+        L.check(L.lib().ndwt_coef_info(self._h, ctypes.byref(lev), ctypes.byref(nb), ctypes.byref(pitch), ctypes.byref(ptr)))
+        return {"level": lev.value, "bands": nb.value, "band_pitch": pitch.value, "dev_ptr": ptr.value}
+
+    def rec(self, out: np.ndarray):
+        assert out.flags.c_contiguous
+        L.check(L.lib().ndwt_coef_rec_host(self.plan._h, self._h, out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def shrink(self, threshold, hard=False):
+        L.check(L.lib().ndwt_coef_shrink(self.plan._h, self._h, float(threshold), int(bool(hard))))
+        return self
+
+    def get(self, out: np.ndarray):
+        assert out.flags.c_contiguous
+        L.check(L.lib().ndwt_coef_get_host(self.plan._h, self._h, out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def release(self):
+        if self._h is not None and self._h.value:
+            L.lib().ndwt_coef_release(self._h)
+            self._h = ctypes.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
 
 class MultiPlan:
@@ -269,12 +325,21 @@ class MultiPlan:
 
     def dec_device(self, x_slabs, level):
         """device-resident form: x_slabs[i] = torch tensor (n_i, ..., n1) on slab i's device -> list of (bands, n_i, ..., n1) tensors.
-        The inputs must be complete (synchronise the streams that produced them); returns when the result is."""
+        Ordered against torch by host synchronisation: every slab device is synchronised before the call; returns when the result is."""
         xs = self._slab_tensors(x_slabs, 0)
         nbt = num_bands(self.ndim, level)
         ys = [torch.empty((nbt,) + tuple(t.shape), dtype=t.dtype, device=t.device) for t in x_slabs]
+        self._sync(x_slabs)
         L.mcheck(L.lib().ndwt_mdec(self._h, xs, self._slab_tensors(ys, nbt), int(level)))
         return ys
+
+    @staticmethod
+    def _sync(tensors):
+        """The plan's private streams are ordered against torch by HOST synchronisation only: the inputs must be complete, and the output
+        tensors just allocated may be blocks the caching allocator recycled from tensors whose kernels are still queued on a torch
+        stream -- every slab device is synchronised before the plan's streams touch them."""
+        for dev in sorted({t.device.index for t in tensors}):
+            torch.cuda.synchronize(dev)
 
     def rec_device(self, y_slabs):
         nbt = int(y_slabs[0].shape[0])
@@ -283,6 +348,7 @@ class MultiPlan:
             raise ValueError(f"{nbt} bands is not a valid {self.ndim}-D coefficient count")
         ys = self._slab_tensors(y_slabs, nbt)
         xs = [torch.empty(tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in y_slabs]
+        self._sync(y_slabs)
         L.mcheck(L.lib().ndwt_mrec(self._h, ys, self._slab_tensors(xs, 0), level))
         return xs
 

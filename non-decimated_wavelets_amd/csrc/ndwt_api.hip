@@ -92,13 +92,18 @@ struct ndwt_plan {
     double shrink_thr;
     void* coef;                        // coefficient scratch of ndwt_denoise (all bands of the last level used), lazily allocated
     size_t coef_bytes;
-    void* taps_den;                    // device tap table of the fused level-1 denoising kernel (TapsDen<float, L>), lazily built
+    void* taps_den;                    // device tap table of the fused level-1 denoising kernel (TapsDen<float, L>), built at plan creation where it applies
+    void* den_a1;                      // ndwt_denoise, fused level 1: the level-1 approximation / its reconstruction -- a scratch of its own (lazily
+                                       // allocated), not `tmp`: dec_impl / rec_impl run in between and may re-allocate that one
     int fused_level1;                  // ndwt_denoise: 1 (default) level 1 in one launch where that is faster (tap lengths <= 6), 2 wherever the
                                        // kernel exists (8 taps too: compute-bound there, +3 %), 0 never (the level-1 detail bands stay in memory)
     // optional per-kernel timing with HIP events on the launch stream (bench.py's roofline figures)
     int profiling;
     std::vector<ProfRec>* prof;
     long long* stamps;                 // diagnostic builds (-DNDWT_STAMPS): device buffer for the per-wave phase cycle sums
+    void* stage[2];                    // device staging of the host-pointer forms: [0] one band (x / the result), [1] all bands; lazily grown,
+    size_t stage_bytes[2];             // kept across calls (ndwt_plan_release_staging frees them)
+    int live_coefs;                    // ndwt_coef handles bound to this plan
     int thin_slab;                     // slab plan whose outer axis is shorter than its filter: slab entry points only
     std::vector<hipEvent_t>* ev_pool;  // profiling events, reused
 };
@@ -1174,6 +1179,8 @@ int ndwt_level_from_bands(int ndim, int64_t bands) {
     return (int)(1 + (bands - nb) / (nb - 1));
 }
 
+static bool den3_eligible(const ndwt_plan* p, int* Lp_out);
+static int den3_taps(ndwt_plan* p, int Lp);
 static int plan_create_impl(ndwt_plan** plan, int ndim, const int64_t* dims, long long global_outer, const char* const* wnames, int dtype,
                             int complexity, int pres_l2_norm, int dilation, int max_level, int device) {
     if (!plan) return fail(NDWT_ERR_INVALID_ARG, "null plan pointer");
@@ -1278,6 +1285,18 @@ static int plan_create_impl(ndwt_plan** plan, int ndim, const int64_t* dims, lon
             }
         }
     }
+    {   // the tap table of the fused level-1 denoising kernel, where that kernel can serve this plan: ndwt_denoise then only enqueues
+        // (den3_eligible is defined further down; the default fused_level1 = 1 admits up to 6 taps, 2 admits 8: build for 8)
+        int Lden = 0;
+        const int keep = p->fused_level1;
+        p->fused_level1 = 2;
+        const bool den = den3_eligible(p, &Lden);
+        p->fused_level1 = keep;
+        if (den && den3_taps(p, Lden) != NDWT_OK) {
+            ndwt_plan_destroy(p);
+            return NDWT_ERR_ALLOC;
+        }
+    }
     *plan = p;
     return NDWT_OK;
 }
@@ -1303,6 +1322,9 @@ int ndwt_plan_destroy(ndwt_plan* p) {
     if (p->tmp) (void)hipFree(p->tmp);
     if (p->coef) (void)hipFree(p->coef);
     if (p->taps_den) (void)hipFree(p->taps_den);
+    if (p->den_a1) (void)hipFree(p->den_a1);
+    for (int i = 0; i < 2; ++i)
+        if (p->stage[i]) (void)hipFree(p->stage[i]);
     for (int i = 0; i < 2; ++i)
         if (p->taps_dev[i]) (void)hipFree(p->taps_dev[i]);
     if (p->prof) {
@@ -1433,6 +1455,22 @@ int64_t ndwt_band_pitch(const ndwt_plan* p) {
     return p->vol / p->comp + (skew > 0 ? skew : 1);
 }
 
+// Device staging of the host-pointer forms, owned by the plan and grown on demand: the gateway calls dec / rec with one configuration
+// thousands of times (README.md:2), and a hipMalloc + hipFree of the 12 GB a 512^3 3-level transform stages costs milliseconds per call.
+static int ensure_stage(ndwt_plan* p, int which, size_t bytes) {
+    if (bytes <= p->stage_bytes[which]) return NDWT_OK;
+    if (p->stage[which]) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(p->stage[which]));
+        p->stage[which] = nullptr;
+        p->stage_bytes[which] = 0;
+    }
+    hipError_t e = hipMalloc(&p->stage[which], bytes);
+    if (e != hipSuccess) return fail(NDWT_ERR_ALLOC, "hipMalloc(%zu bytes) of the staging buffer failed: %s", bytes, hipGetErrorString(e));
+    p->stage_bytes[which] = bytes;
+    return NDWT_OK;
+}
+
 static int host_roundtrip(ndwt_plan* p, bool inverse, const void* src, void* dst, int level) {
     int rc = check_level(p, level);
     if (rc) return rc;
@@ -1440,20 +1478,168 @@ static int host_roundtrip(ndwt_plan* p, bool inverse, const void* src, void* dst
     HIP_TRY(hipSetDevice(p->device));
     const size_t bx = (size_t)p->vol * p->esize;
     const size_t by = bx * (size_t)ndwt_num_bands(p->ndim, level);
-    void *dx = nullptr, *dy = nullptr;
-    if (hipMalloc(&dx, bx) != hipSuccess || hipMalloc(&dy, by) != hipSuccess) {
-        if (dx) (void)hipFree(dx);
-        return fail(NDWT_ERR_ALLOC, "hipMalloc of staging buffers (%zu + %zu bytes) failed", bx, by);
-    }
+    rc = ensure_stage(p, 0, bx);
+    if (rc == NDWT_OK) rc = ensure_stage(p, 1, by);
+    if (rc) return rc;
+    void *dx = p->stage[0], *dy = p->stage[1];
     hipError_t e = hipMemcpy(inverse ? dy : dx, src, inverse ? by : bx, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         rc = inverse ? ndwt_rec(p, dy, dx, level, nullptr) : ndwt_dec(p, dx, dy, level, nullptr);
         if (rc == NDWT_OK) e = hipMemcpy(dst, inverse ? dx : dy, inverse ? bx : by, hipMemcpyDeviceToHost);
     }
-    (void)hipFree(dx);
-    (void)hipFree(dy);
     if (rc) return rc;
     if (e != hipSuccess) return fail(NDWT_ERR_HIP, "staging copy failed: %s", hipGetErrorString(e));
+    return NDWT_OK;
+}
+
+int ndwt_plan_release_staging(ndwt_plan* p) {
+    if (!p) return fail(NDWT_ERR_INVALID_ARG, "null plan");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipDeviceSynchronize());
+    for (int i = 0; i < 2; ++i) {
+        if (p->stage[i]) (void)hipFree(p->stage[i]);
+        p->stage[i] = nullptr;
+        p->stage_bytes[i] = 0;
+    }
+    return NDWT_OK;
+}
+
+// ---- device-resident coefficients (include/ndwt.h: ndwt_coef_*) ----
+struct ndwt_coef {
+    ndwt_plan* plan;
+    int level;
+    long long bands;
+    long long pitch;                   // elements between bands (ndwt_band_pitch)
+    void* dev;
+    size_t bytes;
+};
+
+static int coef_check(const ndwt_plan* p, const ndwt_coef* c) {
+    if (!p || !c) return fail(NDWT_ERR_INVALID_ARG, "null plan / coefficient handle");
+    if (c->plan != p) return fail(NDWT_ERR_INVALID_ARG, "this coefficient handle belongs to another plan");
+    return NDWT_OK;
+}
+
+int ndwt_coef_create(ndwt_plan* p, int level, ndwt_coef** out) {
+    int rc = check_level(p, level);
+    if (rc) return rc;
+    if (!out) return fail(NDWT_ERR_INVALID_ARG, "null output pointer");
+    HIP_TRY(hipSetDevice(p->device));
+    ndwt_coef* c = new ndwt_coef();
+    c->plan = p;
+    c->level = level;
+    c->bands = ndwt_num_bands(p->ndim, level);
+    c->pitch = ndwt_band_pitch(p);
+    c->bytes = (size_t)c->bands * (size_t)c->pitch * (size_t)p->comp * p->esize;
+    hipError_t e = hipMalloc(&c->dev, c->bytes);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(NDWT_ERR_ALLOC, "hipMalloc(%zu bytes) of a coefficient set failed: %s", (size_t)0 + c->bytes, hipGetErrorString(e));
+    }
+    p->live_coefs++;
+    *out = c;
+    return NDWT_OK;
+}
+
+int ndwt_coef_release(ndwt_coef* c) {
+    if (!c) return NDWT_OK;
+    (void)hipSetDevice(c->plan->device);
+    (void)hipDeviceSynchronize();
+    if (c->dev) (void)hipFree(c->dev);
+    c->plan->live_coefs--;
+    delete c;
+    return NDWT_OK;
+}
+
+int ndwt_coef_info(const ndwt_coef* c, int* level, int64_t* bands, int64_t* band_pitch, void** dev_ptr) {
+    if (!c) return fail(NDWT_ERR_INVALID_ARG, "null coefficient handle");
+    if (level) *level = c->level;
+    if (bands) *bands = c->bands;
+    if (band_pitch) *band_pitch = c->pitch;
+    if (dev_ptr) *dev_ptr = c->dev;
+    return NDWT_OK;
+}
+
+// x (host) -> coefficients that STAY on the device: only the signal crosses PCIe (0.5 GB instead of 12.3 GB at 512^3, 3 levels)
+int ndwt_coef_dec_host(ndwt_plan* p, const void* x_host, int level, ndwt_coef** coef) {
+    int rc = check_level(p, level);
+    if (rc) return rc;
+    if (!x_host || !coef) return fail(NDWT_ERR_INVALID_ARG, "null pointer");
+    HIP_TRY(hipSetDevice(p->device));
+    ndwt_coef* c = *coef;
+    if (c && (c->plan != p || c->level != level)) return fail(NDWT_ERR_INVALID_ARG, "the handle passed for reuse holds another plan's / level's coefficients");
+    const bool fresh = c == nullptr;
+    if (fresh) {
+        rc = ndwt_coef_create(p, level, &c);
+        if (rc) return rc;
+    }
+    const size_t bx = (size_t)p->vol * p->esize;
+    rc = ensure_stage(p, 0, bx);
+    hipError_t e = hipSuccess;
+    if (rc == NDWT_OK) e = hipMemcpy(p->stage[0], x_host, bx, hipMemcpyHostToDevice);
+    if (rc == NDWT_OK && e == hipSuccess) rc = ndwt_dec_pitched(p, p->stage[0], c->dev, c->pitch, level, nullptr);
+    if (rc == NDWT_OK && e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (rc != NDWT_OK || e != hipSuccess) {
+        if (fresh) ndwt_coef_release(c);
+        return rc ? rc : fail(NDWT_ERR_HIP, "staging copy failed: %s", hipGetErrorString(e));
+    }
+    *coef = c;
+    return NDWT_OK;
+}
+
+int ndwt_coef_rec_host(ndwt_plan* p, const ndwt_coef* c, void* x_host) {
+    int rc = coef_check(p, c);
+    if (rc) return rc;
+    if (!x_host) return fail(NDWT_ERR_INVALID_ARG, "null pointer");
+    HIP_TRY(hipSetDevice(p->device));
+    const size_t bx = (size_t)p->vol * p->esize;
+    rc = ensure_stage(p, 0, bx);
+    if (rc) return rc;
+    rc = ndwt_rec_pitched(p, c->dev, c->pitch, p->stage[0], c->level, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(x_host, p->stage[0], bx, hipMemcpyDeviceToHost));
+    return NDWT_OK;
+}
+
+int ndwt_coef_shrink(ndwt_plan* p, ndwt_coef* c, double threshold, int mode) {
+    int rc = coef_check(p, c);
+    if (rc) return rc;
+    rc = ndwt_shrink_pitched(p, c->dev, c->pitch, c->level, threshold, mode, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return NDWT_OK;
+}
+
+// the coefficients in the reference's packed layout (band axis last, nd_dwt_mex.c:83) to / from host memory
+int ndwt_coef_get_host(ndwt_plan* p, const ndwt_coef* c, void* y_host) {
+    int rc = coef_check(p, c);
+    if (rc) return rc;
+    if (!y_host) return fail(NDWT_ERR_INVALID_ARG, "null pointer");
+    HIP_TRY(hipSetDevice(p->device));
+    const size_t band = (size_t)p->vol * p->esize, pitch = (size_t)c->pitch * (size_t)p->comp * p->esize;
+    HIP_TRY(hipMemcpy2D(y_host, band, c->dev, pitch, band, (size_t)c->bands, hipMemcpyDeviceToHost));
+    return NDWT_OK;
+}
+
+int ndwt_coef_put_host(ndwt_plan* p, int level, const void* y_host, ndwt_coef** coef) {
+    int rc = check_level(p, level);
+    if (rc) return rc;
+    if (!y_host || !coef) return fail(NDWT_ERR_INVALID_ARG, "null pointer");
+    HIP_TRY(hipSetDevice(p->device));
+    ndwt_coef* c = *coef;
+    if (c && (c->plan != p || c->level != level)) return fail(NDWT_ERR_INVALID_ARG, "the handle passed for reuse holds another plan's / level's coefficients");
+    const bool fresh = c == nullptr;
+    if (fresh) {
+        rc = ndwt_coef_create(p, level, &c);
+        if (rc) return rc;
+    }
+    const size_t band = (size_t)p->vol * p->esize, pitch = (size_t)c->pitch * (size_t)p->comp * p->esize;
+    hipError_t e = hipMemcpy2D(c->dev, pitch, y_host, band, band, (size_t)c->bands, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (fresh) ndwt_coef_release(c);
+        return fail(NDWT_ERR_HIP, "upload of the coefficients failed: %s", hipGetErrorString(e));
+    }
+    *coef = c;
     return NDWT_OK;
 }
 
@@ -1594,9 +1780,11 @@ static int ensure_coef(ndwt_plan* p, size_t need) {
 static int denoise_fused_level1(ndwt_plan* p, int Lp, const float* x, float* out, int level, double threshold, int mode, hipStream_t s) {
     int rc = den3_taps(p, Lp);
     if (rc) return rc;
-    rc = ensure_tmp(p, (size_t)p->vol * sizeof(float) + kApproxSkew);
-    if (rc) return rc;
-    float* a1 = (float*)((char*)p->tmp + kApproxSkew);   // level-1 approximation, then its reconstruction (256 B off the alignment, like the ping-pong scratch)
+    if (!p->den_a1) {
+        hipError_t e = hipMalloc(&p->den_a1, (size_t)p->vol * sizeof(float) + kApproxSkew);
+        if (e != hipSuccess) return fail(NDWT_ERR_ALLOC, "hipMalloc of the level-1 approximation scratch failed: %s", hipGetErrorString(e));
+    }
+    float* a1 = (float*)((char*)p->den_a1 + kApproxSkew);   // level-1 approximation, then its reconstruction (256 B off the alignment, like the ping-pong scratch)
     p->shrink_mode = mode == NDWT_SHRINK_HARD ? 2 : 1;
     p->shrink_thr = threshold;
     rc = den3_launch(p, 0, Lp, x, nullptr, a1, s);
@@ -1652,18 +1840,14 @@ int ndwt_denoise_host(ndwt_plan* p, const void* x, void* out, int level, double 
     if (!x || !out) return fail(NDWT_ERR_INVALID_ARG, "null data pointer");
     HIP_TRY(hipSetDevice(p->device));
     const size_t bx = (size_t)p->vol * p->esize;
-    void *dx = nullptr, *dout = nullptr;
-    if (hipMalloc(&dx, bx) != hipSuccess || hipMalloc(&dout, bx) != hipSuccess) {
-        if (dx) (void)hipFree(dx);
-        return fail(NDWT_ERR_ALLOC, "hipMalloc of the staging buffers (2 x %zu bytes) failed", bx);
-    }
+    rc = ensure_stage(p, 0, 2 * bx);                      // the signal and the result, side by side (kept across calls)
+    if (rc) return rc;
+    void *dx = p->stage[0], *dout = (char*)p->stage[0] + bx;
     hipError_t e = hipMemcpy(dx, x, bx, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         rc = ndwt_denoise(p, dx, dout, level, threshold, mode, nullptr);
         if (rc == NDWT_OK) e = hipMemcpy(out, dout, bx, hipMemcpyDeviceToHost);
     }
-    (void)hipFree(dx);
-    (void)hipFree(dout);
     if (rc) return rc;
     if (e != hipSuccess) return fail(NDWT_ERR_HIP, "staging copy failed: %s", hipGetErrorString(e));
     return NDWT_OK;

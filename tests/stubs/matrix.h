@@ -4,7 +4,7 @@
 #include <stddef.h>
 typedef struct mxArray_tag mxArray;
 typedef size_t mwSize;
-typedef enum { mxSINGLE_CLASS = 7, mxDOUBLE_CLASS = 6 } mxClassID;
+typedef enum { mxSINGLE_CLASS = 7, mxDOUBLE_CLASS = 6, mxUINT64_CLASS = 15 } mxClassID;
 typedef enum { mxREAL = 0, mxCOMPLEX = 1 } mxComplexity;
 #ifndef MX_HAS_INTERLEAVED_COMPLEX
 #define MX_HAS_INTERLEAVED_COMPLEX 0
@@ -13,6 +13,8 @@ int mxIsDouble(const mxArray*);
 int mxIsSingle(const mxArray*);
 int mxIsComplex(const mxArray*);
 int mxIsCell(const mxArray*);
+int mxIsChar(const mxArray*);
+int mxIsUint64(const mxArray*);
 double mxGetScalar(const mxArray*);
 int mxGetString(const mxArray*, char* buf, mwSize buflen);
 mwSize mxGetNumberOfDimensions(const mxArray*);
@@ -21,6 +23,7 @@ size_t mxGetNumberOfElements(const mxArray*);
 mxArray* mxGetCell(const mxArray*, mwSize index);
 void* mxGetData(const mxArray*);
 void* mxGetImagData(const mxArray*);
+mxArray* mxCreateNumericMatrix(mwSize m, mwSize n, mxClassID cls, mxComplexity flag);
 mxArray* mxCreateNumericArray(mwSize ndim, const mwSize* dims, mxClassID cls, mxComplexity flag);
 mxArray* mxCreateUninitNumericArray(mwSize ndim, mwSize* dims, mxClassID cls, mxComplexity flag);   /* R2015a+ */
 #endif

@@ -4,6 +4,7 @@ CPU oracle, the golden fixtures and -- at full size -- size-independent properti
 Tolerances (BASELINE.md section 2 / SURVEY.md 8c): fp64 <= 1e-12 relative to max|c|; fp32 <= 2e-6 relative to
 max|c|; fwd+inv round trip < 1e-6 as a relative l2 norm.
 """
+import ctypes
 import glob
 import os
 
@@ -266,6 +267,63 @@ def test_host_pointer_entry_points_of_the_c_abi():
         p.dec(0, 0, 1)                                     # null pointers are an error, not a crash
     with pytest.raises(ndwt.NdwtError, match="max_level"):
         p.dec(1, 1, 5)
+
+
+@pytest.mark.parametrize("d,sizes,wn,level,precision,cplx", [
+    (3, [72, 40, 33], "db4", 3, "single", False),
+    (2, [130, 64], ["db2", "db3"], 2, "double", False),
+    (3, [24, 20, 16], "db2", 2, "single", True),
+    (1, [4096], "db2", 3, "double", False),
+])
+def test_device_resident_coefficient_handles(d, sizes, wn, level, precision, cplx):
+    """ndwt_coef_*: what the gateway's dec_keep / rec_handle / shrink / fetch / release commands call.  dec with the
+    coefficients left on the device = the host-pointer dec; rec of the handle inverts it; shrink on the handle = shrink of the array;
+    put / get round-trip the reference's packed layout; the plan's staging is reused across calls"""
+    api = __import__("importlib").import_module("non-decimated_wavelets_amd.api")
+    rng = np.random.default_rng(23)
+    wl = [wn] * d if isinstance(wn, str) else wn
+    x = rng.standard_normal(sizes) + (1j * rng.standard_normal(sizes) if cplx else 0)
+    rdt = np.float32 if precision == "single" else np.float64
+    cdt = (np.complex64 if precision == "single" else np.complex128) if cplx else rdt
+    xk = np.ascontiguousarray(np.transpose(x)).astype(cdt)
+    plan = api.Plan(sizes, wl, torch.float32 if precision == "single" else torch.float64, cplx, True, "reference", max_level=level)
+    nb = api.num_bands(d, level)
+    want = np.ascontiguousarray(np.transpose(orc.spatial_dec(x, wl, level, 1)))
+    c = api.Coefficients.dec(plan, xk, level)
+    info = c.info()
+    assert info["level"] == level and info["bands"] == nb and info["band_pitch"] >= xk.size and info["dev_ptr"]
+    y = c.get(np.empty((nb,) + xk.shape, dtype=cdt))
+    assert _relerr(y, want) <= TOL[precision]
+    r = c.rec(np.empty_like(xk))
+    assert _relerr(r, xk) <= 20 * TOL[precision]
+    # the host-pointer dec gives the same array (and reuses the plan's staging: two calls, same buffers)
+    y2 = np.empty_like(y)
+    for _ in range(2):
+        api.L.check(api.L.lib().ndwt_dec_host(plan._h, xk.ctypes.data_as(ctypes.c_void_p), y2.ctypes.data_as(ctypes.c_void_p), level))
+    assert np.array_equal(y, y2)
+    # shrink on the handle, then rec = the denoising step of the host form
+    thr = 0.4
+    c.shrink(thr)
+    den = c.rec(np.empty_like(xk))
+    want_den = np.empty_like(xk)
+    plan.denoise_host(xk.ctypes.data_as(ctypes.c_void_p), want_den.ctypes.data_as(ctypes.c_void_p), level, thr)
+    assert _relerr(den, want_den) <= 20 * TOL[precision]
+    # refill the same handle from another signal; upload arbitrary coefficients
+    c2 = api.Coefficients.dec(plan, 2 * xk, level, reuse=c)
+    assert c2 is c and _relerr(c.get(np.empty_like(y)), 2 * want) <= TOL[precision]
+    cc = rng.standard_normal(y.shape).astype(rdt).astype(cdt)
+    u = api.Coefficients.put(plan, cc, level)
+    assert np.array_equal(u.get(np.empty_like(cc)), cc)
+    want_rec = np.ascontiguousarray(np.transpose(orc.spatial_rec(np.transpose(cc), wl, 1)))
+    assert np.abs(u.rec(np.empty_like(xk)) - want_rec).max() <= 2 * TOL[precision] * max(np.abs(want_rec).max(), np.abs(cc).max())
+    other = api.Plan(sizes, wl, torch.float32 if precision == "single" else torch.float64, cplx, True, "reference", max_level=level)
+    with pytest.raises(ndwt.NdwtError, match="another plan"):
+        api.L.check(api.L.lib().ndwt_coef_rec_host(other._h, u._h, xk.ctypes.data_as(ctypes.c_void_p)))
+    u.release()
+    c.release()
+    plan.release_staging()
+    api.L.check(api.L.lib().ndwt_dec_host(plan._h, xk.ctypes.data_as(ctypes.c_void_p), y2.ctypes.data_as(ctypes.c_void_p), level))
+    assert np.array_equal(y, y2)
 
 
 def test_split_complex_entry_points_match_the_interleaved_transform():

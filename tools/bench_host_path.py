@@ -36,3 +36,16 @@ for name, fn, nbytes in (("dec_host", lambda: lib.check(L.ndwt_dec_host(plan._h,
     dt = (time.perf_counter() - t0) / reps
     print(f"{name:13s} {n}^3 fp32 L{level}: {dt * 1e3:9.1f} ms per call, {nbytes / dt / 1e9:6.1f} GB/s over its {nbytes / 1e9:.2f} GB of host traffic", flush=True)
 print("round trip", float(np.linalg.norm(r - x) / np.linalg.norm(x)))
+# the same solver step with the coefficients behind a device-resident handle (the gateway's dec_keep / shrink / rec_handle): only x crosses
+c = api.Coefficients.dec(plan, x, level)
+for name, fn, nbytes in (("coef dec", lambda: api.Coefficients.dec(plan, x, level, reuse=c), x.nbytes),
+                         ("coef shrink", lambda: c.shrink(0.3), 0),
+                         ("coef rec", lambda: c.rec(r), x.nbytes)):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    dt = (time.perf_counter() - t0) / reps
+    print(f"{name:13s} {n}^3 fp32 L{level}: {dt * 1e3:9.1f} ms per call" + (f", {nbytes / dt / 1e9:6.1f} GB/s over its {nbytes / 1e9:.2f} GB of host traffic" if nbytes else ""),
+          flush=True)
+c.release()
