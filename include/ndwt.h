@@ -253,6 +253,11 @@ int ndwt_mplan_destroy(ndwt_mplan* plan);
 int ndwt_mplan_num_slabs(const ndwt_mplan* plan);
 int ndwt_mplan_slab(const ndwt_mplan* plan, int idx, int* device, int64_t* first_plane, int64_t* planes);
 int ndwt_mplan_set_exchange(ndwt_mplan* plan, int exchange);
+/* 1 (default): the planes moved between slabs travel on per-slab copy streams while the launches that do not need them run (fused 3-D
+ * plans at tap stride 1 whose slabs are thicker than twice the halo; the interior planes first, then the ends / the partial sums first,
+ * then the slab's own planes); 0: exchange, then one launch per slab and level.  Same results either way.  (2: like 1, with the partial
+ * sums staged through the receive buffers even between slabs that share a device -- how the tests run that path on one GPU.) */
+int ndwt_mplan_set_overlap(ndwt_mplan* plan, int overlap);
 int ndwt_mplan_describe(const ndwt_mplan* plan, char* buf, int buflen);   /* slabs, exchange schemes, peer-access findings */
 int ndwt_mdec(ndwt_mplan* plan, const void* const* x_slabs, void* const* y_slabs, int level);
 int ndwt_mrec(ndwt_mplan* plan, const void* const* y_slabs, void* const* x_slabs, int level);

@@ -305,6 +305,11 @@ class MultiPlan:
         L.mcheck(L.lib().ndwt_mplan_set_exchange(self._h, {"scatter": 0, "gather": 1}[scheme]))
         return self
 
+    def set_overlap(self, on):
+        """True (default): copies between slabs on their own streams, overlapped with the launches that do not wait for them"""
+        L.mcheck(L.lib().ndwt_mplan_set_overlap(self._h, int(on)))
+        return self
+
     def describe(self) -> str:
         buf = ctypes.create_string_buffer(512)
         L.mcheck(L.lib().ndwt_mplan_describe(self._h, buf, 512))

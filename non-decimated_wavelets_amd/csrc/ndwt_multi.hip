@@ -11,6 +11,11 @@
 // coefficient slab on its device) and the kernels read and write them in place -- no plan-owned copy of a slab exists.  The host
 // forms stage whole-volume host arrays through plan-owned slab buffers and call the same code.
 //
+// Overlap (round 4; ndwt_mplan_set_overlap, on by default): every slab has a second stream for its copies.  Analysis: the halo planes travel
+// on the copy stream while the planes that need none of them are computed (one launch), then the two ends (one launch).  Scatter synthesis:
+// the partial sums a slab owes its neighbours are computed FIRST (one launch for both margins), travel on the destinations' copy streams
+// while every slab synthesises its own planes, and are added behind that launch.  Slabs are still joined by one event barrier per level.
+//
 // Exchange per level:
 //   analysis   the halo planes of the approximation band only ((L/2-1) s before, (L/2) s after the slab), copied from their
 //              owners into small buffers / the margins of the approximation scratch: bit-identical to one device.
@@ -37,6 +42,8 @@ struct Slab {
     long long z0, n;               // planes [z0, z0 + n) of the outer axis
     ndwt_plan* plan;
     hipStream_t stream;
+    hipStream_t cstream;           // this slab's copies (halo planes in, partial sums in) when the exchange overlaps with compute
+    hipEvent_t copied;             // "the copies queued on cstream for this level have arrived"
     hipEvent_t ready[2];           // "approximation buffer k of this slab is complete" (k = level parity)
     hipEvent_t margins;            // "the partial sums this slab owes its neighbours are computed" (scatter synthesis)
     char* approx[2];               // [halo_max | n | halo_max] planes each: the approximation band between levels
@@ -44,7 +51,8 @@ struct Slab {
     char* ha;                      // ... and after the slab
     char* mb;                      // scatter synthesis: partial sums for the planes before the slab (halo_max planes) ...
     char* ma;                      // ... and after it
-    char* recv;                    // scatter synthesis: planes received from a neighbour, added and reused (halo_max planes)
+    char* recv;                    // scatter synthesis: planes received from the neighbours before they are added (2 * halo_max planes)
+    long long recv_used;           // planes of recv handed out in the current level (overlapped schedule)
     char* gather;                  // gather synthesis: 2^d bands * (n + L - 1) planes, allocated on first use
     char* xbuf;                    // host forms: the slab of x / of the result, allocated on first use
     char* coef;                    // host forms: all bands of the slab, allocated on first use
@@ -68,6 +76,7 @@ struct ndwt_mplan {
     int dilation;
     int exchange;                  // NDWT_EXCHANGE_*
     int fast;                      // the slab plans offer the split-halo analysis and the zero-extended synthesis at tap stride 1
+    int overlap;                   // copies on the slabs' copy streams, overlapped with the launches that do not wait for them
     std::vector<Slab> slabs;
     std::string notes;             // peer-access findings of plan creation (ndwt_mplan_describe)
 };
@@ -107,17 +116,18 @@ static Slab* owner_of(ndwt_mplan* mp, long long gp) {
     return nullptr;
 }
 
-static int copy_run(ndwt_mplan* mp, Slab& to, char* dst, const Slab& from, const char* src, long long planes) {
+static int copy_run(ndwt_mplan* mp, Slab& to, char* dst, const Slab& from, const char* src, long long planes, hipStream_t st = nullptr) {
     const size_t bytes = (size_t)planes * mp->plane_bytes;
-    if (from.device == to.device) MHIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, to.stream));
-    else MHIP(hipMemcpyPeerAsync(dst, to.device, src, from.device, bytes, to.stream));
+    if (!st) st = to.stream;
+    if (from.device == to.device) MHIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
+    else MHIP(hipMemcpyPeerAsync(dst, to.device, src, from.device, bytes, st));
     return NDWT_OK;
 }
 
 // copy `count` planes starting at GLOBAL plane g (periodic) of a per-slab plane array into dst on slab `to`, on `to`'s stream.
 // plane_ptr(slab, local plane) gives the source address; wait_parity >= 0: wait for the source slab's ready[wait_parity] first.
 template <class SrcFn>
-static int copy_planes(ndwt_mplan* mp, Slab& to, char* dst, long long g, long long count, SrcFn plane_ptr, int wait_parity) {
+static int copy_planes(ndwt_mplan* mp, Slab& to, char* dst, long long g, long long count, SrcFn plane_ptr, int wait_parity, hipStream_t st = nullptr) {
     const long long N = mp->dims[mp->ndim - 1];
     long long done = 0;
     while (done < count) {
@@ -126,8 +136,8 @@ static int copy_planes(ndwt_mplan* mp, Slab& to, char* dst, long long g, long lo
         if (!src) return mfail(NDWT_ERR_INVALID_ARG, "plane %lld has no owner", gp);
         long long run = src->z0 + src->n - gp;
         if (run > count - done) run = count - done;
-        if (wait_parity >= 0 && src != &to) MHIP(hipStreamWaitEvent(to.stream, src->ready[wait_parity], 0));
-        MRET(copy_run(mp, to, dst + (size_t)done * mp->plane_bytes, *src, plane_ptr(*src, gp - src->z0), run));
+        if (wait_parity >= 0 && src != &to) MHIP(hipStreamWaitEvent(st ? st : to.stream, src->ready[wait_parity], 0));
+        MRET(copy_run(mp, to, dst + (size_t)done * mp->plane_bytes, *src, plane_ptr(*src, gp - src->z0), run, st));
         done += run;
     }
     return NDWT_OK;
@@ -152,8 +162,10 @@ static int level_barrier(ndwt_mplan* mp, int k) {
         MHIP(hipEventRecord(s.ready[k], s.stream));
     }
     for (auto& s : mp->slabs)
-        for (auto& o : mp->slabs)
+        for (auto& o : mp->slabs) {
             if (&o != &s) MHIP(hipStreamWaitEvent(s.stream, o.ready[k], 0));
+            MHIP(hipStreamWaitEvent(s.cstream, o.ready[k], 0));   // (its own slab's too: the copy stream is ordered by events only)
+        }
     return NDWT_OK;
 }
 
@@ -161,8 +173,18 @@ static int sync_all(ndwt_mplan* mp) {
     for (auto& s : mp->slabs) {
         MHIP(hipSetDevice(s.device));
         MHIP(hipStreamSynchronize(s.stream));
+        MHIP(hipStreamSynchronize(s.cstream));
     }
     return NDWT_OK;
+}
+
+// the overlapped schedules cut a slab into the planes that need no neighbour and the rest: every slab must be thick enough for that
+static bool can_overlap(const ndwt_mplan* mp, long long before, long long after) {
+    if (!mp->overlap || !mp->fast) return false;
+    const long long m = before > after ? before : after;
+    for (auto& s : mp->slabs)
+        if (s.n < 2 * m + 1 || s.n <= before + after) return false;
+    return true;
 }
 
 static int lazy_alloc(Slab& s, char** p, size_t bytes) {
@@ -197,7 +219,36 @@ static int mdec_core(ndwt_mplan* mp, const void* const* x, void* const* y, int l
             void* outs[16];
             outs[0] = lev == level ? y[i] : (void*)(s.approx[wr] + (size_t)H * pb);
             for (int b = 1; b < nb; ++b) outs[b] = (char*)y[i] + (size_t)((1 + (nb - 1) * (level - lev) + (b - 1)) * s.n) * pb;
-            if (lev == 1) {
+            const bool ov = st == 1 && can_overlap(mp, ab, aa);
+            const long long m = ab > aa ? ab : aa;
+            if (ov) {
+                // halo planes on the copy stream; the planes [ab, n - aa) that need none of them meanwhile; then the two ends
+                void* oi[16];
+                for (int b = 0; b < nb; ++b) oi[b] = (char*)outs[b] + (size_t)ab * pb;
+                if (lev == 1) {
+                    auto src = [&](Slab& o, long long lp) -> const char* { return (const char*)x[&o - &mp->slabs[0]] + (size_t)lp * pb; };
+                    const char* xs = (const char*)x[i];
+                    MRET(copy_planes(mp, s, s.hb, s.z0 - ab, ab, src, -1, s.cstream));
+                    MRET(copy_planes(mp, s, s.ha, s.z0 + s.n, aa, src, -1, s.cstream));
+                    MHIP(hipEventRecord(s.copied, s.cstream));
+                    MTRY(ndwt_analysis_level_slab_part(s.plan, xs + (size_t)ab * pb, ab ? xs : nullptr, xs + (size_t)(s.n - aa) * pb, oi, 1, s.n - ab - aa, s.stream));
+                    MHIP(hipStreamWaitEvent(s.stream, s.copied, 0));
+                    // the slab of x is the caller's (no margins around it): the ends are two launches, halo planes from hb / ha
+                    MTRY(ndwt_analysis_level_slab_part(s.plan, xs, ab ? s.hb : nullptr, xs + (size_t)m * pb, outs, 1, m, s.stream));
+                    void* oe[16];
+                    for (int b = 0; b < nb; ++b) oe[b] = (char*)outs[b] + (size_t)(s.n - m) * pb;
+                    MTRY(ndwt_analysis_level_slab_part(s.plan, xs + (size_t)(s.n - m) * pb, ab ? xs + (size_t)(s.n - m - ab) * pb : nullptr, s.ha, oe, 1, m, s.stream));
+                } else {
+                    char* mid = s.approx[rd] + (size_t)H * pb;
+                    auto src = [&](Slab& o, long long lp) -> const char* { return o.approx[rd] + (size_t)(H + lp) * pb; };
+                    MRET(copy_planes(mp, s, mid - (size_t)ab * pb, s.z0 - ab, ab, src, -1, s.cstream));
+                    MRET(copy_planes(mp, s, mid + (size_t)s.n * pb, s.z0 + s.n, aa, src, -1, s.cstream));
+                    MHIP(hipEventRecord(s.copied, s.cstream));
+                    MTRY(ndwt_analysis_level_slab_part(s.plan, mid + (size_t)ab * pb, ab ? mid : nullptr, mid + (size_t)(s.n - aa) * pb, oi, 1, s.n - ab - aa, s.stream));
+                    MHIP(hipStreamWaitEvent(s.stream, s.copied, 0));
+                    MTRY(ndwt_analysis_level_slab_runs(s.plan, mid - (size_t)ab * pb, outs, 1, m, 2, s.n - m, s.stream));   // both ends, one launch
+                }
+            } else if (lev == 1) {
                 // the slab of x is read where it lies; its halo planes come from the neighbours' slabs of x
                 auto src = [&](Slab& o, long long lp) -> const char* { return (const char*)x[&o - &mp->slabs[0]] + (size_t)lp * pb; };
                 if (mp->fast && st == 1) {
@@ -268,7 +319,66 @@ static int mrec_core(ndwt_mplan* mp, const void* const* y, void* const* x, int l
             return (const char*)y[i] + (size_t)((1 + (long long)(nb - 1) * (level - lev) + (b - 1)) * o.n) * pb;
         };
         auto dst_of = [&](Slab& o) -> char* { return lev == 1 ? (char*)x[&o - &mp->slabs[0]] : o.approx[wr] + (size_t)H * pb; };
-        if (scatter) {
+        if (scatter && can_overlap(mp, sa, sb)) {
+            // margins first (one launch: two runs of m planes at the ends of the zero-extended result), so that they travel -- on the
+            // destinations' copy streams -- while every slab synthesises its own planes; the adds follow that launch in stream order
+            const long long m = sa > sb ? sa : sb;
+            size_t i = 0;
+            for (auto& s : mp->slabs) {
+                MHIP(hipSetDevice(s.device));
+                const void* ins[16];
+                for (int b = 0; b < nb; ++b) ins[b] = band_ptr(i, s, b);
+                MTRY(ndwt_synthesis_level_slab_runs(s.plan, ins, s.n, 0, s.n + sa + sb - m, 2, m, s.mb, 1, s.stream));   // mb: [run 0 | run 1]
+                MHIP(hipEventRecord(s.margins, s.stream));
+                MTRY(ndwt_synthesis_level_slab_part(s.plan, ins, s.n, sa, s.n, dst_of(s), 1, s.stream));
+                s.recv_used = 0;
+                ++i;
+            }
+            // the partial sums: run 0 holds planes [0, m) of the zero-extended result (the first sa: owed to the planes before the slab),
+            // run 1 planes [n + sa + sb - m, n + sa + sb) (the last sb: the planes after it).  Copies to other devices go to the
+            // destination's copy stream and a region of its receive buffer of their own; the adds come in slab order, "before" margins
+            // first, behind the destination's own launch: the same fixed order of summation as without overlap.
+            struct Pending { Slab* to; char* dst; const char* src; long long run; };
+            std::vector<Pending> adds;
+            const long long N = mp->dims[mp->ndim - 1];
+            for (auto& from : mp->slabs) {
+                for (int side = 0; side < 2; ++side) {
+                    const long long count = side == 0 ? sa : sb;
+                    const long long g = side == 0 ? from.z0 - sa : from.z0 + from.n;
+                    const char* buf = side == 0 ? from.mb : from.mb + (size_t)(m + (m - sb)) * pb;
+                    long long done = 0;
+                    while (done < count) {
+                        const long long gp = ((g + done) % N + N) % N;
+                        Slab* to = owner_of(mp, gp);
+                        if (!to) return mfail(NDWT_ERR_INVALID_ARG, "plane %lld has no owner", gp);
+                        long long run = to->z0 + to->n - gp;
+                        if (run > count - done) run = count - done;
+                        const char* src = buf + (size_t)done * pb;
+                        char* dst = dst_of(*to) + (size_t)(gp - to->z0) * pb;
+                        if (to->device != from.device || mp->overlap == 2) {   // (2: test hook -- the staged path between slabs of one device)
+                            if (to->recv_used + run > 2 * H) return mfail(NDWT_ERR_UNSUPPORTED, "internal: receive buffer of the overlapped synthesis exhausted");
+                            char* rb = to->recv + (size_t)to->recv_used * pb;
+                            to->recv_used += run;
+                            MHIP(hipSetDevice(to->device));
+                            MHIP(hipStreamWaitEvent(to->cstream, from.margins, 0));
+                            MRET(copy_run(mp, *to, rb, from, src, run, to->cstream));
+                            src = rb;
+                        } else if (to != &from) {
+                            MHIP(hipSetDevice(to->device));
+                            MHIP(hipStreamWaitEvent(to->stream, from.margins, 0));   // same memory: added straight from the producer's buffer
+                        }
+                        adds.push_back({to, dst, src, run});
+                        done += run;
+                    }
+                }
+            }
+            for (auto& s : mp->slabs) {
+                MHIP(hipSetDevice(s.device));
+                MHIP(hipEventRecord(s.copied, s.cstream));
+                MHIP(hipStreamWaitEvent(s.stream, s.copied, 0));
+            }
+            for (auto& a : adds) MRET(add_planes(mp, *a.to, a.dst, a.src, a.run));
+        } else if (scatter) {
             // zero-extended synthesis: plane k of the extended result = global plane z0 - sa + k.  The slab's own n planes go where
             // the result lives; the sa planes before and the sb planes after it are partial sums owed to their owners.
             size_t i = 0;
@@ -324,6 +434,7 @@ int ndwt_mplan_create(ndwt_mplan** out, int ndim, const int64_t* dims, const cha
     mp->ndim = ndim; mp->dtype = dtype; mp->complexity = complexity; mp->max_level = max_level; mp->nb = 1 << ndim;
     mp->dilation = dilation;
     mp->exchange = NDWT_EXCHANGE_SCATTER;
+    mp->overlap = 1;
     for (int a = 0; a < ndim; ++a) mp->dims[a] = dims[a];
     size_t pb = (dtype == NDWT_F32 ? 4 : 8) * (complexity == NDWT_COMPLEX_INTERLEAVED ? 2 : 1);
     for (int a = 0; a + 1 < ndim; ++a) pb *= (size_t)dims[a];
@@ -351,11 +462,15 @@ int ndwt_mplan_create(ndwt_mplan** out, int ndim, const int64_t* dims, const cha
         if (!ndwt_plan_slab_fast(s.plan)) mp->fast = 0;
         hipError_t e = hipSetDevice(s.device);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.cstream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.copied, hipEventDisableTiming);
         for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&s.ready[k], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s.margins, hipEventDisableTiming);
         for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipMalloc((void**)&s.approx[k], (size_t)(s.n + 2 * mp->halo_max) * pb);
-        for (char** p : {&s.hb, &s.ha, &s.mb, &s.ma, &s.recv})
+        for (char** p : {&s.hb, &s.ha, &s.ma})
             if (e == hipSuccess) e = hipMalloc((void**)p, (size_t)mp->halo_max * pb);
+        for (char** p : {&s.mb, &s.recv})               // mb: both margins of the overlapped synthesis (two runs); recv: a region per sender
+            if (e == hipSuccess) e = hipMalloc((void**)p, (size_t)(2 * mp->halo_max) * pb);
         if (e != hipSuccess) { rc = mfail(NDWT_ERR_ALLOC, "device %d: %s", s.device, hipGetErrorString(e)); break; }
         for (auto& o : mp->slabs)                        // peer access where the runtime offers it (same-device pairs need none)
             if (o.device != s.device) {
@@ -393,6 +508,8 @@ int ndwt_mplan_destroy(ndwt_mplan* mp) {
             if (s.ready[k]) (void)hipEventDestroy(s.ready[k]);
         }
         if (s.margins) (void)hipEventDestroy(s.margins);
+        if (s.copied) (void)hipEventDestroy(s.copied);
+        if (s.cstream) { (void)hipStreamSynchronize(s.cstream); (void)hipStreamDestroy(s.cstream); }
         for (char* p : {s.hb, s.ha, s.mb, s.ma, s.recv, s.gather, s.xbuf, s.coef})
             if (p) (void)hipFree(p);
         if (s.stream) (void)hipStreamDestroy(s.stream);
@@ -417,11 +534,18 @@ int ndwt_mplan_set_exchange(ndwt_mplan* mp, int exchange) {
     return NDWT_OK;
 }
 
+int ndwt_mplan_set_overlap(ndwt_mplan* mp, int overlap) {
+    if (!mp) return mfail(NDWT_ERR_INVALID_ARG, "null plan");
+    mp->overlap = overlap == 2 ? 2 : (overlap ? 1 : 0);
+    return NDWT_OK;
+}
+
 int ndwt_mplan_describe(const ndwt_mplan* mp, char* buf, int buflen) {
     if (!mp || !buf || buflen < 1) return mfail(NDWT_ERR_INVALID_ARG, "bad arguments");
     const bool scatter = mp->exchange == NDWT_EXCHANGE_SCATTER && mp->fast && mp->dilation == NDWT_DILATION_REFERENCE;
-    snprintf(buf, (size_t)buflen, "%d slabs; analysis: halo planes of the approximation band%s; synthesis: %s; %s", (int)mp->slabs.size(),
+    snprintf(buf, (size_t)buflen, "%d slabs; analysis: halo planes of the approximation band%s; synthesis: %s; %s; %s", (int)mp->slabs.size(),
              mp->fast ? ", slabs read in place" : "", scatter ? "scatter-add of one band of partial sums" : "gather of the halo planes of all bands",
+             (mp->overlap && mp->fast) ? "exchange overlapped with the planes that do not wait for it (where every slab is thick enough)" : "exchange, then compute",
              mp->notes.empty() ? "peer access between all devices" : mp->notes.c_str());
     return NDWT_OK;
 }

@@ -1054,6 +1054,21 @@ def test_single_process_multi_device_plan(dims, wn, level, precision, cplx, dila
         assert np.array_equal(r, mp.rec(c))                                           # deterministic: a fixed order of summation
         assert _relerr(mp.rec(yk), xk) <= 20 * TOL[precision]
     mp.set_exchange("scatter")
+    # the overlapped schedule (copy streams; interior planes, then the ends / partial sums first, then the own planes) against the
+    # plain one: the same kernels on the same planes and the same order of summation -- the same bits (2: partial sums staged
+    # through the receive buffers, the path between different devices)
+    fast = "slabs read in place" in mp.describe()        # fused 3-D slab plans: the only ones with an overlapped schedule
+    assert ("overlapped" in mp.describe()) == fast
+    ref = {}
+    for ov in (0, 1, 2):
+        mp.set_overlap(ov)
+        yo, ro = mp.dec(xk, level), mp.rec(c)
+        if ov == 0:
+            assert "exchange, then compute" in mp.describe()
+            ref = {"y": yo, "r": ro}
+        assert np.array_equal(yo, ref["y"]) and np.array_equal(ro, ref["r"]), ov
+        assert np.array_equal(yo, yk)
+    mp.set_overlap(1)
     # device-resident form: one tensor per slab, read and written in place
     dev = torch.device("cuda", 0)
     xs = [torch.from_numpy(xk[z0:z0 + n]).to(dev) for _, z0, n in sl]
