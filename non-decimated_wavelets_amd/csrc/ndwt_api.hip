@@ -829,23 +829,24 @@ template <typename T> static int dec_impl(ndwt_plan* p, const T* x, T* y, long l
         // (variant_fwd 11: tests and A/B runs on small images)
         if (level >= 2 && p->ndim == 2 && cascade2_eligible(p, &Lp) && p->dims[1] >= 3 * (Lp - 1) &&
             (p->vol > (6LL << 20) || p->variant_fwd == 11 || p->variant_fwd == 10)) {
-            int lev = 1;
-            while (level - lev + 1 >= 2) {                // levels lev .. lev + n - 1 in one launch
+            int lev = 1, pp = 0;                          // pp: the scratch volume the next launch writes (they alternate launch by launch: a
+            while (level - lev + 1 >= 2) {                // launch never writes the approximation it reads); levels lev .. lev + n - 1 in one launch
                 const int n = (level - lev + 1 >= 3 && Lp <= 8) ? 3 : 2;   // (12 taps: two levels fit the 256 registers, three do not)
                 const int last = lev + n - 1;
                 float* out[10];
-                out[0] = (last == level) ? y : (float*)p->approx[(last - 1) & 1];
+                out[0] = (last == level) ? y : (float*)p->approx[pp];
                 for (int l = 0; l < n; ++l)               // cascade level l (0 = first) is transform level lev + l
                     for (int b = 1; b < nb; ++b) out[1 + 3 * (n - 1 - l) + (b - 1)] = y + (long long)(1 + (nb - 1) * (level - (lev + l)) + (b - 1)) * bs;
                 const int rc = cascade2_run(p, Lp, n, cur, out, s);
                 if (rc == -1) break;                      // not this data (alignment): one launch per level from here on
                 if (rc) return rc;
                 cur = out[0];
+                pp ^= 1;
                 lev = last + 1;
             }
-            for (; lev <= level; ++lev) {
+            for (; lev <= level; ++lev, pp ^= 1) {
                 T* out[16];
-                out[0] = (lev == level) ? y : (T*)p->approx[(lev - 1) & 1];
+                out[0] = (lev == level) ? y : (T*)p->approx[pp];
                 for (int b = 1; b < nb; ++b) out[b] = y + (long long)(1 + (nb - 1) * (level - lev) + (b - 1)) * bs;
                 int rc = analysis_level<T>(p, cur, out, level_stride(p, lev), false, s);
                 if (rc) return rc;
@@ -911,7 +912,7 @@ template <typename T> static int rec_impl(ndwt_plan* p, const T* y, long long bs
         // (variant_inv 9: one launch per level; 11: cascade whatever the image size; not while thresholding is fused into the loads)
         if (level >= 2 && p->ndim == 2 && p->variant_inv != 9 && !p->shrink_mode && cascade2_eligible(p, &Lp) && Lp <= 8 &&
             p->dims[1] >= 3 * (Lp - 1) && (p->vol > (6LL << 20) || p->variant_inv == 11 || p->variant_inv == 12)) {
-            int lev = level;                              // coarsest level still to be synthesised
+            int lev = level, pp = 0;                      // coarsest level still to be synthesised; pp: the scratch volume the next launch writes
             while (lev >= 2) {
                 const int n = lev >= 3 ? 3 : 2;           // levels lev, lev - 1, .. lev - n + 1 in one launch
                 const float* in[10];
@@ -919,18 +920,19 @@ template <typename T> static int rec_impl(ndwt_plan* p, const T* y, long long bs
                 for (int c = 0; c < n; ++c)               // cascade level c (0 = coarsest) is transform level lev - c
                     for (int b = 1; b < nb; ++b) in[1 + 3 * c + (b - 1)] = y + (long long)(1 + (nb - 1) * (level - (lev - c)) + (b - 1)) * bs;
                 const int low = lev - n + 1;
-                float* dst = (low == 1) ? x : (float*)p->approx[(low - 1) & 1];
+                float* dst = (low == 1) ? x : (float*)p->approx[pp];
                 const int rc = cascade2_rec_run(p, Lp, n, in, dst, s);
                 if (rc == -1) break;
                 if (rc) return rc;
                 prev = dst;
+                pp ^= 1;
                 lev = low - 1;
             }
-            for (; lev >= 1; --lev) {
+            for (; lev >= 1; --lev, pp ^= 1) {
                 const T* in[16];
                 in[0] = prev;
                 for (int b = 1; b < nb; ++b) in[b] = y + (long long)(1 + (nb - 1) * (level - lev) + (b - 1)) * bs;
-                T* dst = (lev == 1) ? x : (T*)p->approx[(lev - 1) & 1];
+                T* dst = (lev == 1) ? x : (T*)p->approx[pp];
                 int rc = synthesis_level<T>(p, in, dst, level_stride(p, lev), false, s);
                 if (rc) return rc;
                 prev = dst;

@@ -808,6 +808,7 @@ def test_fused2d_kernels_at_baseline_config2_shape():
     ([256, 96], "db4", 3),                       # two waves along x (224 columns each), three levels in one launch
     ([512, 130], ["db2", "db3"], 2),             # mixed wavelets padded to 6 taps, two levels
     ([64, 200], "db6", 4),                       # 12 taps: two launches of two levels
+    ([636, 52], ["db3", "db6"], 5),              # ... two launches of two levels and a single one: the scratch volumes alternate per LAUNCH
     ([1024, 64], "db1", 5),                      # 2 taps, five levels: a launch of three and one of two
     ([260, 80], "db3", 4),                       # four levels: three in one launch, the fourth on the one-level kernel
     ([232, 77], "db4", 3),
