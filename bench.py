@@ -24,7 +24,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s is the measured copy ceiling)
-TRAFFIC_PROFILE = "r03_traffic.json"   # committed rocprofv3 --pmc figures of the headline command (fallback when the live passes cannot run)
+TRAFFIC_PROFILE = "r04_traffic.json"   # committed rocprofv3 --pmc figures of the headline command (fallback when the live passes cannot run)
 KERNEL_NAMES = {0: "fused_analysis", 1: "fused_synthesis", 2: "axis_analysis", 3: "axis_synthesis"}
 
 

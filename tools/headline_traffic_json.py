@@ -36,7 +36,7 @@ out = {
               "requests that gfx950 issues for 128-B lines)",
     "fused_synthesis": entry(False, "INV"), "fused_analysis": entry(False, "FWD"),
     "pitched": {"band_pitch": "prod(dims) + 64 elements (ndwt_band_pitch)", "fused_synthesis": entry(True, "INV"), "fused_analysis": entry(True, "FWD")},
-    "note": "round 3; rocprofv3 --kernel-trace --stats of the packed command: profiles/r03_kernel_stats.csv.  bench.py measures the same two "
+    "note": "round " + tag[1:3].lstrip("0") + "; rocprofv3 --kernel-trace --stats of the packed command: profiles/" + tag[:3] + "_kernel_stats.csv.  bench.py measures the same two "
             "counters live (two rocprofv3 child passes) and falls back to this file only when rocprofv3 is missing.",
 }
 print(json.dumps(out, indent=1))
