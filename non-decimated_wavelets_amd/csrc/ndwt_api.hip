@@ -894,6 +894,11 @@ static int cascade2_rec_run(ndwt_plan* p, int Lp, int nlev, const float* const* 
     a.nyc = (a.n2 + a.ychunk - 1) / a.ychunk;
     float* outs[1] = {out};
     a.nt = nt_store_ok<float>(a.rs, a.rs, 0, outs, 1);
+    if (p->shrink_mode) {                                 // ndwt_denoise: threshold the detail bands as their rows are loaded
+        a.shrink_on = 1;
+        a.shrink_thr = (float)p->shrink_thr;
+        a.shrink_hard = p->shrink_mode == 2;
+    }
     const void* td = p->taps_dev[1];
     if (!td) return fail(NDWT_ERR_UNSUPPORTED, "plan has no device tap table");
     prof_begin(p, NDWT_KERNEL_FUSED_SYNTHESIS, s);
@@ -909,8 +914,8 @@ template <typename T> static int rec_impl(ndwt_plan* p, const T* y, long long bs
     const T* prev = y;   // band 0
     if constexpr (sizeof(T) == 4) {
         int Lp = 0;
-        // (variant_inv 9: one launch per level; 11: cascade whatever the image size; not while thresholding is fused into the loads)
-        if (level >= 2 && p->ndim == 2 && p->variant_inv != 9 && !p->shrink_mode && cascade2_eligible(p, &Lp) && Lp <= 8 &&
+        // (variant_inv 9: one launch per level; 11 / 12: cascade whatever the image size, one / two rows of band loads in flight)
+        if (level >= 2 && p->ndim == 2 && p->variant_inv != 9 && cascade2_eligible(p, &Lp) && Lp <= 8 &&
             p->dims[1] >= 3 * (Lp - 1) && (p->vol > (6LL << 20) || p->variant_inv == 11 || p->variant_inv == 12)) {
             int lev = level, pp = 0;                      // coarsest level still to be synthesised; pp: the scratch volume the next launch writes
             while (lev >= 2) {

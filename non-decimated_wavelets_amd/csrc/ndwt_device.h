@@ -2773,6 +2773,8 @@ template <typename T> struct Fused2CIArgs {
     int ychunk, ntx, nyc;
     int rs;
     int nt;
+    T shrink_thr;          // ndwt_denoise: soft (or, shrink_hard, hard) thresholding of every detail band as its rows are loaded; 0 = off
+    int shrink_on, shrink_hard;
 };
 
 template <typename T, int L_, int NLEV_, int PD_ = 1, int WPE_ = 2> struct Inv2C {
@@ -2877,6 +2879,15 @@ template <typename T, int L_, int NLEV_, int PD_ = 1, int WPE_ = 2> struct Inv2C
     template <int K, class Exec>
     static NDWT_DEV void row(Exec& ex, const RegT& rt, const Args& a, int x0, int ybeg, int yend, int rr0, int p, int nrows) {
         const int y = rr0 + p - NLEV * RH;
+        if (a.shrink_on) {                                // thresholding fused into the reconstruction (the detail rows this step consumes)
+            ex.each([&](int, State& st) __attribute__((always_inline)) {
+                NDWT_SFOR(c, NLEV)
+                    NDWT_SFOR(b, 3)
+                        shrink4_flat<T>(st.raw[c][K % PD][1 + b], a.shrink_thr, a.shrink_hard);
+                    NDWT_SEND
+                NDWT_SEND
+            });
+        }
         NDWT_SFOR(c, NLEV)
             ex.each([&](int tid, State& st) __attribute__((always_inline)) { level<c, K>(ex, st, rt, a, x0, y, y >= ybeg && y < yend, tid); });
         NDWT_SEND

@@ -852,6 +852,16 @@ def test_cascaded_2d_synthesis_against_oracle(sizes, wn, level, depth):
         w._plan(False, level, cg.device).set_variant(inv=variant)
         res[variant] = w.rec(cg)
         assert np.abs(res[variant].cpu().numpy() - want).max() <= 2 * TOL["single"] * max(np.abs(want).max(), np.abs(c).max()), variant
+    # ndwt_denoise on the cascaded kernels (thresholding fused into Inv2C's loads) against one launch per level
+    xg = _colmajor_gpu(rng.standard_normal(sizes), "single")
+    den = {}
+    for variant in (11 if depth == 1 else 12, 9):
+        w = ndwt.nd_dwt_2D(wn, sizes, "pres_l2_norm", 1, "precision", "single")
+        w._plan(False, level, xg.device).set_variant(fwd=11 if variant != 9 else 9, inv=variant)
+        den[variant] = {m: w.denoise(xg, level, 0.3, m) for m in ("soft", "hard")}
+    dv = list(den.values())
+    for m in ("soft", "hard"):
+        assert float((dv[0][m] - dv[1][m]).abs().max()) <= 4 * TOL["single"] * float(dv[1][m].abs().max()), m
     a, b = list(res.values())
     # (the one-level kernels run 4 / 8 / 12 taps as packed FMAs like the cascade -- the same bits -- and other tap lengths as scalar ones)
     Lp = max(len(ndwt.wave_filters(v)[0]) for v in wl)
