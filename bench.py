@@ -212,6 +212,24 @@ def one_rank_share(sh, torch, dev, wname, level, whole_ms, n_local=64, steps=100
     return out
 
 
+def rccl_self_exchange(wname, level):
+    """The same slab step with every exchange a real RCCL batch: a child process (torch.distributed is initialised in it, not here) creates a
+    1-rank `nccl` group and runs the sharded driver with its self-segments routed through grouped send / receive (tools/host_overhead_nccl.py).
+    Nothing travels (sender = receiver = this GPU), so the difference to the local-copy figures is what six (eight) RCCL batches cost on the
+    GPU's timeline and on the host: the floor of the exchange cost of an 8-GPU run.  None if the child fails."""
+    import re
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_overhead_nccl.py"), wname, str(level)], capture_output=True, text=True,
+                           timeout=240, env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300)))
+        out = {}
+        for m in re.finditer(r"exchange=(local copies|RCCL send/recv to self) overlap=(True|False): enqueue ([0-9.]+) ms per step, complete ([0-9.]+) ms", r.stdout):
+            key = ("rccl_self" if m.group(1).startswith("RCCL") else "local_copies") + ("_overlap" if m.group(2) == "True" else "_one_piece")
+            out[key] = {"ms_per_dec_rec": float(m.group(4)), "host_enqueue_ms": float(m.group(3))}
+        return out or None
+    except Exception:
+        return None
+
+
 def live_traffic(extra_args):
     """HBM-side bytes per launch of the fused kernels of THIS command line, measured now: two child processes
     `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --steps 2 --warmup 1 ...` (separate passes, the program directly after
@@ -336,6 +354,12 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    # The interpreter's cyclic garbage collector is kept out of the timed regions: a full collection walks every object torch has created
+    # (38 ms measured) and, landing in a 20-step loop of 0.9-ms steps of the sharded driver, doubles the figure (tools/host_overhead_nccl.py).
+    # Everything alive now is moved to the permanent generation; what the steps allocate is still collected, cheaply.
+    import gc
+    gc.collect()
+    gc.freeze()
     # ---- timed region: exactly a.steps steps, no per-kernel event recording inside it ----
     fence()
     t0 = time.perf_counter()
@@ -516,6 +540,11 @@ def main():
             share = {"cfg3": one_rank_share(sh, torch, dev, "db4", 3, dts * 1e3)}
             if "ms_per_step" in others.get("cfg4_transform", {}):
                 share["cfg4"] = one_rank_share(sh, torch, dev, "db6", 4, others["cfg4_transform"]["ms_per_step"])
+            rs = rccl_self_exchange("db4", 3)                     # (child process; this one never initialises torch.distributed at N = 1)
+            if rs:
+                for k, v in rs.items():
+                    v["x8_equivalent"] = round(dts * 1e3 / v["ms_per_dec_rec"], 2)
+                share["cfg3"]["with_rccl_batches_to_self"] = rs
             out["one_rank_share"] = share
         except Exception as e:
             out["one_rank_share"] = {"error": f"{type(e).__name__}: {e}"[:200]}

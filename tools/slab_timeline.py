@@ -17,6 +17,11 @@ if sys.argv[1] == "run":
     sh = importlib.import_module("non-decimated_wavelets_amd.sharded")
     dev = torch.device("cuda", 0)
     x = torch.randn(64, 512, 512, device=dev)
+    if len(sys.argv) > 3 and sys.argv[3] == "after_one_piece":     # allocation history: an engine of the other schedule ran (and died) before
+        e0 = sh.ShardedNdDwt(["db4"] * 3, [512, 512, 64], pres_l2_norm=True, precision="single", device=dev, overlap=False)
+        for _ in range(10):
+            r = e0.rec(e0.dec(x, 3))
+        torch.cuda.synchronize()
     eng = sh.ShardedNdDwt(["db4"] * 3, [512, 512, 64], pres_l2_norm=True, precision="single", device=dev, overlap=sys.argv[2] == "1",
                           two_streams=False)
     for _ in range(10):
