@@ -214,16 +214,18 @@ def one_rank_share(sh, torch, dev, wname, level, whole_ms, n_local=64, steps=100
 
 def rccl_self_exchange(wname, level):
     """The same slab step with every exchange a real RCCL batch: a child process (torch.distributed is initialised in it, not here) creates a
-    1-rank `nccl` group and runs the sharded driver with its self-segments routed through grouped send / receive (tools/host_overhead_nccl.py).
-    Nothing travels (sender = receiver = this GPU), so the difference to the local-copy figures is what six (eight) RCCL batches cost on the
-    GPU's timeline and on the host: the floor of the exchange cost of an 8-GPU run.  None if the child fails."""
+    1-rank `nccl` group and runs the sharded driver with its self-segments routed through grouped send / receive (tools/host_overhead_nccl.py),
+    once through torch.distributed's point-to-point ops and once as RCCL calls on the transform's own stream (ndwt_comm_*).  Nothing travels
+    (sender = receiver = this GPU), so the difference to the local-copy figures is what six (eight) RCCL batches cost on the GPU's timeline and
+    on the host: the floor of the exchange cost of an 8-GPU run.  None if the child fails."""
     import re
     try:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_overhead_nccl.py"), wname, str(level)], capture_output=True, text=True,
                            timeout=240, env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300)))
         out = {}
-        for m in re.finditer(r"exchange=(local copies|RCCL send/recv to self) overlap=(True|False): enqueue ([0-9.]+) ms per step, complete ([0-9.]+) ms", r.stdout):
-            key = ("rccl_self" if m.group(1).startswith("RCCL") else "local_copies") + ("_overlap" if m.group(2) == "True" else "_one_piece")
+        for m in re.finditer(r"exchange=(local copies|RCCL send/recv to self|direct RCCL to self) overlap=(True|False): enqueue ([0-9.]+) ms per step, complete ([0-9.]+) ms", r.stdout):
+            # torch_p2p_self: torch.distributed batch_isend_irecv (RCCL on its own stream); direct_rccl_self: ndwt_comm_exchange on the transform's stream
+            key = {"l": "local_copies", "R": "torch_p2p_self", "d": "direct_rccl_self"}[m.group(1)[0]] + ("_overlap" if m.group(2) == "True" else "_one_piece")
             out[key] = {"ms_per_dec_rec": float(m.group(4)), "host_enqueue_ms": float(m.group(3))}
         return out or None
     except Exception:

@@ -265,6 +265,22 @@ int ndwt_mdec_host(ndwt_mplan* plan, const void* x_host, void* y_host, int level
 int ndwt_mrec_host(ndwt_mplan* plan, const void* y_host, void* x_host, int level);
 const char* ndwt_mplan_last_error(void);
 
+/* ---- exchange of the one-process-per-GPU driver: RCCL point-to-point calls on the caller's stream ------------------------------------
+ * (ncclSend / ncclRecv inside ncclGroupStart / ncclGroupEnd between ring neighbours.)  torch.distributed's
+ * batch_isend_irecv runs its RCCL work on a stream of its own: every exchange then pays two cross-stream dependencies (40 + 14 us around a
+ * 15-us RCCL kernel on one MI355X, six times per dec + rec step of 0.83 ms); enqueued on the stream that runs the transform, the same grouped
+ * send / receive is one more kernel in stream order.  librccl is opened at run time (no link-time dependency).
+ * Rank 0 obtains a 128-byte id (ndwt_comm_unique_id) and hands it to every rank by whatever means the host has (the Python driver
+ * broadcasts it through torch.distributed); every rank then calls ndwt_comm_create (collective).  ndwt_comm_exchange enqueues one group of
+ * sends / receives: op i moves bytes[i] bytes at ptrs[i] to (is_send[i] != 0) or from rank peers[i]; between two ranks, sends and receives are
+ * matched in the order they are listed.  Stream-ordered: the buffers may be reused by later work on `stream` without further waiting. */
+typedef struct ndwt_comm ndwt_comm;
+int ndwt_comm_unique_id(void* id128);
+int ndwt_comm_create(ndwt_comm** comm, const void* id128, int nranks, int rank, int device);
+int ndwt_comm_destroy(ndwt_comm* comm);
+int ndwt_comm_exchange(ndwt_comm* comm, int nops, const int* is_send, void* const* ptrs, const int64_t* bytes, const int* peers, void* stream);
+const char* ndwt_comm_last_error(void);
+
 /* ---- errors ------------------------------------------------------------------------------------------ */
 const char* ndwt_last_error(void); /* thread-local message of the last failing call */
 const char* ndwt_version(void);

@@ -28,7 +28,8 @@ EXPORTS = [
     "ndwt_synthesis_level_slab_part", "ndwt_analysis_level_slab_runs", "ndwt_synthesis_level_slab_runs", "ndwt_last_error",
     "ndwt_version", "ndwt_mplan_create", "ndwt_mplan_destroy", "ndwt_mplan_num_slabs", "ndwt_mplan_slab", "ndwt_mdec_host",
     "ndwt_mrec_host", "ndwt_mplan_last_error", "ndwt_mdec", "ndwt_mrec", "ndwt_mplan_set_exchange", "ndwt_mplan_describe", "ndwt_plan_slab_fast", "ndwt_dec_pitched", "ndwt_rec_pitched", "ndwt_shrink_pitched", "ndwt_band_pitch", "ndwt_slab_segments",
-    "ndwt_plan_release_staging", "ndwt_mplan_set_overlap", "ndwt_coef_create", "ndwt_coef_release", "ndwt_coef_info", "ndwt_coef_dec_host", "ndwt_coef_rec_host",
+    "ndwt_plan_release_staging", "ndwt_mplan_set_overlap", "ndwt_comm_unique_id", "ndwt_comm_create", "ndwt_comm_destroy", "ndwt_comm_exchange",
+    "ndwt_comm_last_error", "ndwt_coef_create", "ndwt_coef_release", "ndwt_coef_info", "ndwt_coef_dec_host", "ndwt_coef_rec_host",
     "ndwt_coef_shrink", "ndwt_coef_get_host", "ndwt_coef_put_host",
 ]
 
@@ -129,6 +130,12 @@ def lib() -> ctypes.CDLL:
     L.ndwt_mplan_describe.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
     L.ndwt_plan_slab_fast.argtypes = [ctypes.c_void_p]
     L.ndwt_plan_release_staging.argtypes = [ctypes.c_void_p]
+    L.ndwt_comm_unique_id.argtypes = [ctypes.c_void_p]
+    L.ndwt_comm_create.argtypes = [c_void_pp, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.ndwt_comm_destroy.argtypes = [ctypes.c_void_p]
+    L.ndwt_comm_exchange.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), c_void_pp, ctypes.POINTER(ctypes.c_int64),
+                                     ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]
+    L.ndwt_comm_last_error.restype = ctypes.c_char_p
     L.ndwt_coef_create.argtypes = [ctypes.c_void_p, ctypes.c_int, c_void_pp]
     L.ndwt_coef_release.argtypes = [ctypes.c_void_p]
     L.ndwt_coef_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), c_void_pp]

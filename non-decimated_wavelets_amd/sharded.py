@@ -126,6 +126,60 @@ class HipSlabEngine:
         return buf[0, :sa], buf[1, m - sb:]
 
 
+class DirectRccl:
+    """The exchange as RCCL point-to-point calls on the CURRENT stream (include/ndwt.h: ndwt_comm_*), without the two cross-stream
+    dependencies torch.distributed's NCCL work pays per batch (its own stream): 20 us instead of 69 us per exchange on one MI355X.  Created
+    collectively over a torch.distributed group of any backend: rank 0's id travels through broadcast_object_list."""
+
+    def __init__(self, group, device):
+        import ctypes
+        self._ct = ctypes
+        self._h = ctypes.c_void_p(None)
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        ident = [None]
+        err = None
+        if rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            if L.lib().ndwt_comm_unique_id(buf) != L.NDWT_OK:
+                err = L.lib().ndwt_comm_last_error().decode()
+            ident = [bytes(buf.raw)]
+        dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None and group is not dist.group.WORLD else 0, group=group)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if err is None and L.lib().ndwt_comm_create(ctypes.byref(self._h), ident[0], world, rank, idx) != L.NDWT_OK:
+            err = L.lib().ndwt_comm_last_error().decode()
+            self._h = ctypes.c_void_p(None)
+        # usable only if EVERY rank has it
+        flags = [None] * world
+        dist.all_gather_object(flags, err, group=group)
+        bad = [f"rank {r}: {e}" for r, e in enumerate(flags) if e is not None]
+        if bad:
+            self.close()
+            raise RuntimeError("direct RCCL transport unavailable (" + "; ".join(bad) + ")")
+        self.device = device
+
+    def exchange(self, ops):
+        """ops: [(is_send, contiguous tensor, peer rank)] in the group's segment order -> one ncclGroup on the current stream"""
+        if not ops:
+            return
+        ct, n = self._ct, len(ops)
+        rc = L.lib().ndwt_comm_exchange(self._h, n, (ct.c_int * n)(*[1 if o[0] else 0 for o in ops]), (ct.c_void_p * n)(*[o[1].data_ptr() for o in ops]),
+                                        (ct.c_int64 * n)(*[o[1].numel() * o[1].element_size() for o in ops]), (ct.c_int * n)(*[o[2] for o in ops]),
+                                        ct.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        if rc != L.NDWT_OK:
+            raise RuntimeError("RCCL exchange failed: " + L.lib().ndwt_comm_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            L.lib().ndwt_comm_destroy(self._h)
+            self._h = self._ct.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 _SKEW_BYTES = 256
 
 
@@ -161,7 +215,7 @@ def _bands_in_place(y):
 
 class ShardedNdDwt:
     def __init__(self, wname, sizes, pres_l2_norm=False, precision="double", dilation="reference", group=None, device=None,
-                 engine=None, synthesis_scheme="auto", overlap="auto", band_pitch="auto", two_streams=False, _self_p2p=False):
+                 engine=None, synthesis_scheme="auto", overlap="auto", band_pitch="auto", two_streams=False, transport="torch", _self_p2p=False):
         """band_pitch: layout of the coefficient slab dec() returns on the GPU -- 'auto' (default): the bands of one allocation, each
         contiguous, prod(local shape) + 256 bytes apart (a strided view: index it like any tensor; .contiguous() packs it; rec()
         takes either) -- the layout the synthesis kernels read 10 % faster; 'packed': a contiguous tensor, for
@@ -218,6 +272,16 @@ class ShardedNdDwt:
         # instead of adding its own (one MI355X, cfg3's slab: see DESIGN.md section 5)
         self.two_streams = bool(two_streams) and self.device.type == "cuda"
         self._side = None
+        # transport of the exchange between ranks: "torch" = torch.distributed point-to-point ops (RCCL on the GPUs, its own stream);
+        # "rccl" = RCCL calls on the current stream (DirectRccl; GPU slabs in an initialised process group, not over gloo staging);
+        # tune() measures both
+        if transport not in ("torch", "rccl"):
+            raise ValueError("transport must be 'torch' or 'rccl'")
+        self.transport = "torch"
+        self._comm = None
+        if transport == "rccl":
+            self._open_direct()                           # raises if any rank cannot
+            self.transport = "rccl"
         self.tuned = None                       # tune(): {"schedule": chosen, "ms_<schedule>": t, ...}
 
     # ---------------------------------------------------------------------------------- plumbing
@@ -282,6 +346,7 @@ class ShardedNdDwt:
         if ha is None:
             ha = t.new_empty(shp[:ax] + [after] + shp[ax + 1:])
         ops, keep, post, local = [], [], [], []
+        direct = self.transport == "rccl"
         for q, side, p, k0, l0, n in self._plan_exchange(before, after):
             if p != self.rank and q != self.rank:
                 continue
@@ -295,15 +360,18 @@ class ShardedNdDwt:
                 if self._host_stage:
                     buf = buf.cpu()
                 keep.append(buf)
-                ops.append(dist.P2POp(dist.isend, buf, self._global_rank(q), self.group))
+                ops.append((True, buf, q) if direct else dist.P2POp(dist.isend, buf, self._global_rank(q), self.group))
             if q == self.rank:
                 if dst.is_contiguous() and not self._host_stage:
-                    ops.append(dist.P2POp(dist.irecv, dst, self._global_rank(p), self.group))
+                    ops.append((False, dst, p) if direct else dist.P2POp(dist.irecv, dst, self._global_rank(p), self.group))
                 else:
                     buf = torch.empty(dst.shape, dtype=dst.dtype, device="cpu" if self._host_stage else dst.device)
-                    ops.append(dist.P2POp(dist.irecv, buf, self._global_rank(p), self.group))
+                    ops.append((False, buf, p) if direct else dist.P2POp(dist.irecv, buf, self._global_rank(p), self.group))
                     post.append(lambda dst=dst, buf=buf: dst.copy_(buf))
         self._apply(False, local)
+        if direct:
+            self._comm.exchange(ops)                      # in stream order on the current stream: nothing to wait for afterwards
+            return hb, ha, ([], post, keep)
         works = dist.batch_isend_irecv(ops) if ops else []
         return hb, ha, (works, post, keep)
 
@@ -319,6 +387,7 @@ class ShardedNdDwt:
         """Posts the sends of the partial planes this rank owes (part_before: for the `before` planes ahead of its
         slab, part_after: for the `after` planes behind it) and the receives of what it is owed."""
         ops, adds_local, adds_recv, keep = [], [], [], []
+        direct = self.transport == "rccl"
         parts = (part_before, part_after)
         # rank q PRODUCES partial planes for the global planes around its slab; the owner p ADDS them
         for q, side, p, k0, l0, n in self._plan_exchange(before, after):
@@ -330,15 +399,18 @@ class ShardedNdDwt:
                 if self._host_stage:
                     part = part.cpu()
                     keep.append(part)
-                ops.append(dist.P2POp(dist.isend, part, self._global_rank(p), self.group))
+                ops.append((True, part, p) if direct else dist.P2POp(dist.isend, part, self._global_rank(p), self.group))
             if p == self.rank:
                 ref = parts[side]
                 if self._host_stage:
                     buf = torch.empty([n] + list(ref.shape[1:]), dtype=ref.dtype, device="cpu")
                 else:
                     buf = self._buf(("scatter_recv", q, side, k0), [n] + list(ref.shape[1:]), ref)
-                ops.append(dist.P2POp(dist.irecv, buf, self._global_rank(q), self.group))
+                ops.append((False, buf, q) if direct else dist.P2POp(dist.irecv, buf, self._global_rank(q), self.group))
                 adds_recv.append((l0, n, buf))
+        if direct:
+            self._comm.exchange(ops)
+            return [], adds_local + adds_recv, (parts, keep)
         works = dist.batch_isend_irecv(ops) if ops else []
         return works, adds_local + adds_recv, (parts, keep)
 
@@ -386,6 +458,14 @@ class ShardedNdDwt:
             cur.wait_event(last.record_event())
         self._last_stream = cur
 
+    def _open_direct(self):
+        """the direct RCCL transport, created once (collective); raises RuntimeError on every rank if one of them cannot"""
+        if self._comm is None:
+            if self.device.type != "cuda" or not dist.is_initialized() or self._host_stage:
+                raise RuntimeError("the direct RCCL transport needs GPU slabs in an initialised (non-gloo-staged) process group")
+            self._comm = DirectRccl(self.group, self.device)
+        return self._comm
+
     def _side_stream(self):
         if self._side is None:
             self._side = torch.cuda.Stream(self.device, priority=-1)
@@ -398,9 +478,10 @@ class ShardedNdDwt:
         return 1 if self.dilation == "reference" else 1 << (lev - 1)
 
     def tune(self, x_local, level, steps=3):
-        """Measures dec + rec of this slab under the three schedules -- one piece per level (exchange, then one launch), the exchange
+        """Measures dec + rec of this slab under every schedule -- one piece per level (exchange, then one launch), the exchange
         overlapped with the interior planes on one stream, the same with the edge pieces and the exchange on a high-priority side
-        stream -- and keeps the fastest; the same on every rank (the times are MAX-reduced over the group, so all ranks take the same
+        stream; on GPUs each with torch.distributed's point-to-point ops and with RCCL calls on the transform's own stream (DirectRccl) --
+        and keeps the fastest; the same on every rank (the times are MAX-reduced over the group, so all ranks take the same
         decision from the same numbers).  Collective: every rank of the group calls it with its own slab and the same level.
         Returns the record it stores in self.tuned."""
         import time
@@ -416,10 +497,17 @@ class ShardedNdDwt:
             if distributed:
                 dist.barrier(self.group)
 
-        modes = [("one_piece", False, False), ("overlap", True, False)] + ([("overlap_two_streams", True, True)] if cuda else [])
+        modes = [("one_piece", False, False, "torch"), ("overlap", True, False, "torch")] + ([("overlap_two_streams", True, True, "torch")] if cuda else [])
+        note = None
+        if cuda and dist.is_initialized() and not self._host_stage and (self.world > 1 or self._self_p2p):
+            try:                                          # the exchange as RCCL calls on the transform's own stream (collective: all ranks or none)
+                self._open_direct()
+                modes += [("rccl_one_piece", False, False, "rccl"), ("rccl_overlap_two_streams", True, True, "rccl")]
+            except RuntimeError as exc:
+                note = str(exc)[:200]
         ms = []
-        for _, ov, ts in modes:
-            self.overlap, self.two_streams = ov, ts
+        for _, ov, ts, tr in modes:
+            self.overlap, self.two_streams, self.transport = ov, ts, tr
             self.rec(self.dec(x_local, level))            # buffers, plans, communicators of this schedule
             fence()
             t0 = time.perf_counter()
@@ -432,8 +520,10 @@ class ShardedNdDwt:
             dist.all_reduce(red, op=dist.ReduceOp.MAX, group=self.group)
             ms = [float(v) for v in red]
         best = min(range(len(modes)), key=lambda i: ms[i])
-        _, self.overlap, self.two_streams = modes[best]
+        _, self.overlap, self.two_streams, self.transport = modes[best]
         self.tuned = {"schedule": modes[best][0], "steps": steps, **{f"ms_{m[0]}": round(t, 4) for m, t in zip(modes, ms)}}
+        if note:
+            self.tuned["direct_rccl"] = note
         return self.tuned
 
     # --------------------------------------------------------------------------------- transform

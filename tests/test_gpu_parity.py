@@ -1133,18 +1133,22 @@ def _rccl_self_worker(rank, world, port, q):
     try:
         sh = importlib.import_module("non-decimated_wavelets_amd.sharded")
         errs, info = [], []
+        xs3 = None
         for sizes, wn, level in (([72, 40, 50], "db4", 3), ([136, 64, 40], "db6", 2), ([24, 20, 12, 18], "db4", 2)):
             d = len(sizes)
             torch.manual_seed(11)
             xs = torch.randn(*reversed(sizes), device=dev)
+            xs3 = xs if xs3 is None else xs3
             w = _cls(d)(wn, sizes, "pres_l2_norm", 1, "precision", "single")
             yref = w.dec(xs.permute(*reversed(range(d))), level).permute(*reversed(range(d + 1)))
             c = torch.randn_like(yref)
             want = w.rec(c.permute(*reversed(range(d + 1)))).permute(*reversed(range(d)))
-            for overlap, two in (((True, False), (True, True), (False, False)) if d == 3 else ((False, False),)):
+            cases = ((True, False, "torch"), (True, True, "torch"), (False, False, "torch"), (False, False, "rccl"), (True, True, "rccl")) if d == 3 else \
+                    ((False, False, "torch"), (False, False, "rccl"))
+            for overlap, two, transport in cases:             # transport "rccl": RCCL calls on the transform's own stream (ndwt_comm_*)
                 try:
                     eng = sh.ShardedNdDwt([wn] * d, sizes, pres_l2_norm=True, precision="single", device=dev, overlap=overlap,
-                                          two_streams=two, _self_p2p=True)
+                                          two_streams=two, transport=transport, _self_p2p=True)
                     assert eng.scheme == "scatter" and not eng._host_stage and eng.world == 1
                     for rep in range(3):                            # later calls reuse the cached scratch / receive buffers
                         yl = eng.dec(xs, level)
@@ -1154,6 +1158,13 @@ def _rccl_self_worker(rank, world, port, q):
                         errs.append((max(e_dec, e_rec2), e_rec))
                 except Exception as exc:                            # e.g. RCCL refusing a send to self: reported, not hidden
                     info.append(f"{sizes} {wn} overlap={overlap}: {type(exc).__name__}: {exc}"[:300])
+        # tune(): every schedule of both transports measured, one kept; the result still equals the single-device transform
+        eng = sh.ShardedNdDwt(["db4"] * 3, [72, 40, 50], pres_l2_norm=True, precision="single", device=dev, _self_p2p=True)
+        rec = eng.tune(xs3, 3, steps=2)
+        if not all(k in rec for k in ("ms_one_piece", "ms_overlap", "ms_overlap_two_streams", "ms_rccl_one_piece", "ms_rccl_overlap_two_streams")):
+            info.append(f"tune() did not measure every schedule: {rec}")
+        e_t = float((eng.rec(eng.dec(xs3, 3)) - xs3).abs().max())
+        errs.append((0.0, e_t))
         torch.cuda.synchronize(dev)
         q.put((rank, errs, info))
     finally:
@@ -1164,7 +1175,7 @@ def test_rccl_branch_of_the_sharded_driver_on_one_gpu():
     """the `nccl` branch of sharded.py executed for real: a 1-rank RCCL group, segments to self through P2POp"""
     (rank, errs, info), = _run_ranks(_rccl_self_worker, 1)
     assert not info, info
-    assert len(errs) == 21
+    assert len(errs) == 37
     for e_a, e_b in errs:
         assert e_a <= 4e-6 and e_b <= 2e-5, errs
 

@@ -24,9 +24,10 @@ x = torch.randn(64, 512, 512, device=dev)
 import gc  # noqa: E402
 gc.collect()
 gc.freeze()          # (a full collection of the interpreter's garbage collector takes 38 ms with torch loaded: not inside a 100-step loop)
-for p2p in (False, True):
+for p2p, transport in ((False, "torch"), (True, "torch"), (True, "rccl")):
     for overlap in (False, True):
-        eng = sh.ShardedNdDwt([wname] * 3, [512, 512, 64], pres_l2_norm=True, precision="single", device=dev, overlap=overlap, _self_p2p=p2p)
+        eng = sh.ShardedNdDwt([wname] * 3, [512, 512, 64], pres_l2_norm=True, precision="single", device=dev, overlap=overlap, _self_p2p=p2p,
+                              transport=transport, two_streams=(overlap and transport == "rccl"))
         for _ in range(5):
             r = eng.rec(eng.dec(x, level))
         torch.cuda.synchronize()
@@ -36,6 +37,6 @@ for p2p in (False, True):
         t1 = time.perf_counter()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        print(f"{wname} L{level} exchange={'RCCL send/recv to self' if p2p else 'local copies'} overlap={overlap}: enqueue {(t1 - t0) * 10:.3f} ms per step, "
+        print(f"{wname} L{level} exchange={('RCCL send/recv to self' if transport == 'torch' else 'direct RCCL to self') if p2p else 'local copies'} overlap={overlap}: enqueue {(t1 - t0) * 10:.3f} ms per step, "
               f"complete {(t2 - t0) * 10:.3f} ms per step", flush=True)
 dist.destroy_process_group()
