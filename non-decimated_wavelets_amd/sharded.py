@@ -135,6 +135,7 @@ class DirectRccl:
         import ctypes
         self._ct = ctypes
         self._h = ctypes.c_void_p(None)
+        self._cache = {}
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         ident = [None]
         err = None
@@ -162,8 +163,15 @@ class DirectRccl:
         if not ops:
             return
         ct, n = self._ct, len(ops)
-        rc = L.lib().ndwt_comm_exchange(self._h, n, (ct.c_int * n)(*[1 if o[0] else 0 for o in ops]), (ct.c_void_p * n)(*[o[1].data_ptr() for o in ops]),
-                                        (ct.c_int64 * n)(*[o[1].numel() * o[1].element_size() for o in ops]), (ct.c_int * n)(*[o[2] for o in ops]),
+        # the driver's exchange buffers are allocated once, so the same few argument lists come back every step: built once, looked up after
+        key = tuple((o[0], o[1].data_ptr(), o[1].numel() * o[1].element_size(), o[2]) for o in ops)
+        args = self._cache.get(key)
+        if args is None:
+            if len(self._cache) > 256:
+                self._cache.clear()
+            args = self._cache[key] = ((ct.c_int * n)(*[1 if k[0] else 0 for k in key]), (ct.c_void_p * n)(*[k[1] for k in key]),
+                                       (ct.c_int64 * n)(*[k[2] for k in key]), (ct.c_int * n)(*[k[3] for k in key]))
+        rc = L.lib().ndwt_comm_exchange(self._h, n, args[0], args[1], args[2], args[3],
                                         ct.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         if rc != L.NDWT_OK:
             raise RuntimeError("RCCL exchange failed: " + L.lib().ndwt_comm_last_error().decode())
