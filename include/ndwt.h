@@ -138,7 +138,7 @@ int ndwt_plan_release_staging(ndwt_plan* plan);
  * 3 ms of compute.  A solver that only needs rec(shrink(dec(x))) -- or that keeps y between iterations -- can leave the coefficients
  * on the device behind an opaque handle: only the signal crosses the link.  The handle is bound to the plan that made it (same
  * dims / wavelets / precision); it owns a pitched coefficient array (ndwt_band_pitch) and must be released before its plan is
- * destroyed.  All calls are synchronous on the null stream, like the other host-pointer forms. */
+ * destroyed (ndwt_plan_destroy refuses while handles of the plan are alive).  All calls are synchronous on the null stream, like the other host-pointer forms. */
 typedef struct ndwt_coef ndwt_coef;
 int ndwt_coef_create(ndwt_plan* plan, int level, ndwt_coef** coef);                       /* uninitialised coefficients of `level` levels */
 int ndwt_coef_release(ndwt_coef* coef);

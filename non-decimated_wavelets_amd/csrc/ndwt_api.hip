@@ -1323,6 +1323,8 @@ int ndwt_plan_create_slab(ndwt_plan** plan, int ndim, const int64_t* dims_local,
 
 int ndwt_plan_destroy(ndwt_plan* p) {
     if (!p) return NDWT_OK;
+    if (p->live_coefs > 0)                                // (a handle points back at its plan: release the handles first)
+        return fail(NDWT_ERR_INVALID_ARG, "%d coefficient handle(s) of this plan are still alive: ndwt_coef_release them first", p->live_coefs);
     (void)hipSetDevice(p->device);
     for (int i = 0; i < 2; ++i)
         if (p->approx_base[i]) (void)hipFree(p->approx_base[i]);

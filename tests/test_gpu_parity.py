@@ -319,6 +319,7 @@ def test_device_resident_coefficient_handles(d, sizes, wn, level, precision, cpl
     other = api.Plan(sizes, wl, torch.float32 if precision == "single" else torch.float64, cplx, True, "reference", max_level=level)
     with pytest.raises(ndwt.NdwtError, match="another plan"):
         api.L.check(api.L.lib().ndwt_coef_rec_host(other._h, u._h, xk.ctypes.data_as(ctypes.c_void_p)))
+    assert api.L.lib().ndwt_plan_destroy(plan._h) != 0 and "still alive" in api.L.lib().ndwt_last_error().decode()   # handles first
     u.release()
     c.release()
     plan.release_staging()
