@@ -206,7 +206,7 @@ def one_rank_share(sh, torch, dev, wname, level, whole_ms, n_local=64, steps=100
                     "roundtrip_rel_l2": float(torch.linalg.vector_norm((r - x).double()) / torch.linalg.vector_norm(x.double()))}
         del eng
     eng = sh.ShardedNdDwt([wname] * 3, [512, 512, n_local], pres_l2_norm=True, precision="single", device=dev)   # overlap="auto"
-    out["auto"] = eng.tune(x, level, steps=10)
+    out["auto"] = eng.tune(x, level)
     del eng, x
     torch.cuda.empty_cache()
     return out

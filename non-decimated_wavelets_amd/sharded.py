@@ -485,7 +485,7 @@ class ShardedNdDwt:
     def _stride(self, lev):
         return 1 if self.dilation == "reference" else 1 << (lev - 1)
 
-    def tune(self, x_local, level, steps=3):
+    def tune(self, x_local, level, steps=10):
         """Measures dec + rec of this slab under every schedule -- one piece per level (exchange, then one launch), the exchange
         overlapped with the interior planes on one stream, the same with the edge pieces and the exchange on a high-priority side
         stream; on GPUs each with torch.distributed's point-to-point ops and with RCCL calls on the transform's own stream (DirectRccl) --
@@ -514,15 +514,23 @@ class ShardedNdDwt:
             except RuntimeError as exc:
                 note = str(exc)[:200]
         ms = []
-        for _, ov, ts, tr in modes:
-            self.overlap, self.two_streams, self.transport = ov, ts, tr
-            self.rec(self.dec(x_local, level))            # buffers, plans, communicators of this schedule
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                self.rec(self.dec(x_local, level))
-            fence()
-            ms.append((time.perf_counter() - t0) / steps * 1e3)
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.collect()
+        gc.disable()                                      # (a full collection of the interpreter's GC is 40 ms with torch loaded: not inside a timing)
+        try:
+            for _, ov, ts, tr in modes:
+                self.overlap, self.two_streams, self.transport = ov, ts, tr
+                self.rec(self.dec(x_local, level))        # buffers, plans, communicators of this schedule
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    self.rec(self.dec(x_local, level))
+                fence()
+                ms.append((time.perf_counter() - t0) / steps * 1e3)
+        finally:
+            if gc_was_on:
+                gc.enable()
         if distributed:
             red = torch.tensor(ms, dtype=torch.float64, device=self.device if dist.get_backend(self.group) == "nccl" else "cpu")
             dist.all_reduce(red, op=dist.ReduceOp.MAX, group=self.group)
