@@ -114,6 +114,39 @@ def cpu_baseline(level, wname, sample_sizes, workers):
     return float(np.prod(sample_sizes)) / dt / 1e6, dt
 
 
+def cpu_spatial_baseline(level, wname, sample_sizes, threads):
+    """The same transform as a signal-domain filter bank in C / OpenMP on the host cores, fp32 (oracle/ndwt_spatial.c, SURVEY 8d: `our
+    spatial CPU backend on all cores`): what a CPU implementation that does not go through the DFT reaches.  Built here with -march=native
+    (the portable library of the test suite is the fallback).  Returns (Mvoxels/s of the best of 3 dec+rec, seconds of that pass, threads)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import tempfile
+    import numpy as np
+    import ndwt_spatial as sp
+    try:
+        lib = sp.load(sp.build(native=True, out_dir=tempfile.mkdtemp(prefix="ndwt_spatial_")))
+    except Exception:
+        lib = sp.load()
+    had = lib.ndwt_c_max_threads()
+    lib.ndwt_c_set_threads(threads)
+    try:
+        x = np.random.default_rng(0).standard_normal(tuple(reversed(sample_sizes)), dtype=np.float32)   # C order: outermost axis first
+        wn = [wname] * len(sample_sizes)
+        y = np.empty((sp.num_bands(len(sample_sizes), level),) + x.shape, dtype=np.float32)
+        r = np.empty_like(x)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            sp.dec_planar(x, wn, level, 1, out=y, lib=lib)
+            sp.rec_planar(y, wn, 1, level=level, out=r, lib=lib)
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        err = float(np.abs(r - x).max())
+        assert err < 2e-5, err
+    finally:
+        lib.ndwt_c_set_threads(had)
+    return float(x.size) / best / 1e6, best, threads
+
+
 def measure_config(api, torch, dev, d, sizes, wname, level, steps, warmup):
     """One non-headline BASELINE configuration on this GPU, packed (reference) coefficient layout: wall-clock mean and hipEvent
     median per dec+rec step, whole-step roofline fraction and the per-kernel HIP-event averages.  Runs AFTER the headline's
@@ -571,6 +604,14 @@ def main():
             v2, secs2 = cpu_baseline(level, a.wname, sample, cores)
             out["cpu_baseline"]["all_cores"] = {"value": round(v2, 2), "unit": "Mvoxels/s", "cores": cores,
                                                 "sample": f"the same sample, workers={cores} (os.cpu_count()); {secs2:.1f} s"}
+        try:
+            v3, secs3, th = cpu_spatial_baseline(level, a.wname, sample, cores)
+            out["cpu_baseline"]["spatial_port"] = {"value": round(v3, 1), "unit": "Mvoxels/s", "cores": th, "kind": "port",
+                                                   "sample": f"the same sample in fp32 as a signal-domain filter bank in C / OpenMP (oracle/ndwt_spatial.c: "
+                                                             f"periodic correlations axis by axis, not the reference's DFT-domain algorithm), {th} threads, "
+                                                             f"best of 3 dec+rec; {secs3:.2f} s"}
+        except Exception as e:                                    # (no gcc / no OpenMP on the host: the reference-algorithm figures stand alone)
+            out["cpu_baseline"]["spatial_port"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist:
