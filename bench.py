@@ -72,6 +72,31 @@ def self_launch(a):
     sys.exit(r.returncode)
 
 
+def usable_cores():
+    """Cores this process may actually run on: the smaller of os.cpu_count(), the scheduler affinity mask and the cgroup's CPU quota (a GPU
+    box hands one job a share of its host -- 16 of 256 cores on the pool's one-GPU boxes -- and a pool of os.cpu_count() threads on
+    that share runs SLOWER than one of the share's size: 4.4 against 24 Mvoxels/s for the OpenMP filter bank)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: [t.strip(), None])):
+        try:
+            with open(path) as f:
+                quota, period = parse(f.read())
+            if period is None:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = f.read().strip()
+            if quota not in ("max", "-1") and int(quota) > 0:
+                n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+            break
+        except (OSError, ValueError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(level, wname, sample_sizes, workers):
     """The reference's algorithm (FFT-domain fast convolution, op sequence of mex/nddwt.c) restated with scipy.fft on
     the host cores, complex128 like the mex path -- kind 'port'.  Timed on a bounded sample of the workload.
@@ -584,7 +609,8 @@ def main():
         except Exception as e:
             out["one_rank_share"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cores = os.cpu_count() or 1
+        host = os.cpu_count() or 1
+        cores = usable_cores()                                    # affinity mask / cgroup quota: the share of the host this job may use
         if a.cpu_full:
             sample = list(sizes)                                  # the whole workload (512^3: ~160 GiB of host memory, minutes)
         elif d == 2:
@@ -598,12 +624,13 @@ def main():
         v, secs = cpu_baseline(level, a.wname, sample, w_ref)
         desc = (f"{'x'.join(map(str, sample))} ({'the whole workload' if sample == list(sizes) else 'bounded sample of ' + shape}) fp64/complex128 "
                 f"{a.wname} {level} levels dec+rec, FFT-domain restatement of mex/nddwt.c (scipy.fft/pocketfft in place of FFTW)")
-        out["cpu_baseline"] = {"value": round(v, 2), "unit": "Mvoxels/s", "cores": w_ref, "host_cpu_count": cores, "kind": "port",
+        out["cpu_baseline"] = {"value": round(v, 2), "unit": "Mvoxels/s", "cores": w_ref, "host_cpu_count": host, "usable_cores": cores, "kind": "port",
                                "sample": f"{desc}; workers={w_ref} = the reference's fftw_plan_with_nthreads(8); {secs:.1f} s"}
         if cores > w_ref:
             v2, secs2 = cpu_baseline(level, a.wname, sample, cores)
             out["cpu_baseline"]["all_cores"] = {"value": round(v2, 2), "unit": "Mvoxels/s", "cores": cores,
-                                                "sample": f"the same sample, workers={cores} (os.cpu_count()); {secs2:.1f} s"}
+                                                "sample": f"the same sample, workers={cores} (every core this job may use: affinity mask / cgroup quota; "
+                                                          f"the host has {host}); {secs2:.1f} s"}
         try:
             v3, secs3, th = cpu_spatial_baseline(level, a.wname, sample, cores)
             out["cpu_baseline"]["spatial_port"] = {"value": round(v3, 1), "unit": "Mvoxels/s", "cores": th, "kind": "port",

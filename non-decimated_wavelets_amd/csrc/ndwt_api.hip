@@ -524,7 +524,12 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     if constexpr (sizeof(T) == 4) {
         if (use_y) {
             rc = ew == 4 ? (vec4 ? launch_inv3y4_f32(a, Lp, variant == 5 ? 1 : 2, td, s) : -1)
-                 : ew == 2 ? launch_inv3yc_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s) : launch_inv3y_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s, uniform_yz(p) && variant != 9);
+                 : ew == 2 ? launch_inv3yc_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s)
+                 // real data on rows of whole groups of 4, 10 .. 20 taps: the x stage in scatter form (512^3 per launch db5 1.18 -> 1.09 ms,
+                 // db6 1.34 -> 1.23, db9 2.66 -> 2.41, db10 3.08 -> 2.87; 8 taps: 1.04 either way, the gather form stays.  A/B: variant_inv
+                 // 10 = scatter form for 8 taps too, 11 = gather form for every tap length)
+                 : (vec4 && variant != 11 && (Lp >= 10 || variant == 10)) ? launch_inv3ys_f32(a, Lp, variant == 5 ? 1 : 2, td, s, uniform_yz(p)) : -1;
+            if (rc == -1 && ew == 1) rc = launch_inv3y_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s, uniform_yz(p) && variant != 9);
             if (rc == -1) {                               // the geometry above is this kernel's: never fall through to another one with it
                 prof_end(p, s, rc);
                 return fail(NDWT_ERR_UNSUPPORTED, "pair-packed synthesis kernel not instantiated for tap length %d", Lp);

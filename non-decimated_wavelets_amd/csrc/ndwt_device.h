@@ -241,6 +241,19 @@ NDWT_DEV long long batch_base(int b, int bsplit, long long bs1, long long bs2) {
     return bsplit > 0 ? (long long)(b % bsplit) * bs1 + (long long)(b / bsplit) * bs2 : (long long)b * bs1;
 }
 
+// A wave-uniform 64-bit value the compiler holds in VGPRs (batch_base: the divisions of its index arithmetic run on the vector ALU), moved
+// to SGPRs: what is derived from it per plane -- base pointer + plane offset of every band -- is then scalar arithmetic instead of one
+// v_lshl_add_u64 and two v_readfirstlane_b32 per band and plane (27 of the ~380 vector instructions per wave and plane of Inv3Y<12>)
+NDWT_DEV long long uniform_ll(long long v) {
+#ifndef NDWT_HOST_EMU
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+#else
+    return v;
+#endif
+}
+
 NDWT_DEV int xcd_remap(int bid, int nblocks) {
     const int nx = 8;
     int q = nblocks / nx, r = nblocks % nx;
@@ -384,6 +397,25 @@ struct PkF32 {
 #else
         acc.x += a[SELA] * (NEGLO ? -tp[SWAP ? 1 : 0] : tp[SWAP ? 1 : 0]);
         acc.y += a[SELA] * (NEGHI ? -tp[SWAP ? 0 : 1] : tp[SWAP ? 0 : 1]);
+#endif
+    }
+    // acc = (a[SELA], a[SELA]) * (t0, t1): the first term of a sum (fma_bt without the zeroed accumulator it would need)
+    template <int SELA, bool SWAP, bool NEGLO, bool NEGHI> static NDWT_DEV void mul_bt(v2& acc, const v2 a, const v2 tp) {
+#ifndef NDWT_HOST_EMU
+#define NDWT_PKM(A, S, NS, NL, NH)                                                                                          \
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[" #A "," #S "] op_sel_hi:[" #A "," #NS "] neg_lo:[0," #NL "] neg_hi:[0," #NH "]" \
+            : "=v"(acc) : "v"(a), "s"(tp))
+        if constexpr (SELA == 0 && !SWAP) NDWT_PKM(0, 0, 1, 0, 0);
+        else if constexpr (SELA == 1 && !SWAP) NDWT_PKM(1, 0, 1, 0, 0);
+        else if constexpr (SELA == 0 && NEGLO) NDWT_PKM(0, 1, 0, 1, 0);
+        else if constexpr (SELA == 1 && NEGLO) NDWT_PKM(1, 1, 0, 1, 0);
+        else if constexpr (SELA == 0) NDWT_PKM(0, 1, 0, 0, 1);
+        else NDWT_PKM(1, 1, 0, 0, 1);
+#undef NDWT_PKM
+        static_assert(SWAP ? (NEGLO != NEGHI) : (!NEGLO && !NEGHI), "forms used by the x stages");
+#else
+        acc.x = a[SELA] * (NEGLO ? -tp[SWAP ? 1 : 0] : tp[SWAP ? 1 : 0]);
+        acc.y = a[SELA] * (NEGHI ? -tp[SWAP ? 0 : 1] : tp[SWAP ? 0 : 1]);
 #endif
     }
     // acc += x * (t, t), t = tp[HI], negated if NEG
@@ -1361,8 +1393,14 @@ template <typename T, int L> struct Taps3Y {             // the first two member
 // exist only as inputs of the neighbouring lanes' x analysis).
 // UNIYZ_: the y and z axes carry the same taps (the same wavelet, the usual case): the z stage reads the y tap pairs, which frees L SGPRs
 // (the kernel holds (L + 1) + L tap pairs, 8 band pointers and its loop scalars in ~100 SGPRs and spills the rest to VGPR lanes).
+// XSC_: the x stage in SCATTER form (real data).  The gather form moves every neighbouring sample a lane needs into the lane (v_mov_b32_dpp:
+// 8 per band with 8 taps, 12 with 12 -- as many again as a third of its packed FMAs), once per BAND.  In scatter form a lane multiplies only
+// its own 4 samples -- into partial sums of the output pairs they reach, its neighbours' included -- and the partial sums travel instead:
+// one v_add_f32_dpp per float and hop, once per output STREAM (the x-low and x-high band of a stream add up before they move), and the first
+// term of every sum is a v_pk_mul_f32 (no zeroed accumulators): 48 shifted adds instead of 96 moves + 32 zeroings per lane and plane with
+// 12 taps, the same 208 packed multiply-adds.  The order of summation differs from the gather form's (results agree to rounding).
 template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 4, int DEPTH_ = 1, int EW_ = 1, int ZLDS_ = 0, int XH_ = 0,
-          bool UNIYZ_ = false> struct Inv3Y {
+          bool UNIYZ_ = false, bool XSC_ = false> struct Inv3Y {
     static_assert(sizeof(T) == 4, "pair-packed synthesis: float only (v_pk_fma_f32)");
     static_assert(EW_ == 1 || EW_ == 2 || EW_ == 4, "real data, interleaved complex data / a level dilated by 2, a level dilated by 4");
     static constexpr int L = L_, TX = TX_, TY = TY_, NT = NT_, WPE = WPE_, EW = EW_;
@@ -1376,6 +1414,14 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
     static constexpr int GL = (LH * EW + 3) / 4, GR = (RH * EW + 3) / 4;
     static constexpr int XH = XH_;
     static constexpr bool UNIYZ = UNIYZ_;
+    static constexpr bool XSC = XSC_;
+    static_assert(!XSC || (EW_ == 1 && XH_ == 0), "scatter x stage: real data, rows without extra lanes");
+    // scatter x stage: own sample c (0..3) reaches the output pair P = (2P, 2P+1), counted from the lane's first x, through the tap pair
+    // K = c + LH - 2P (0 <= K <= L); pair P belongs to the lane floor(P / 2) away, as its pair P mod 2
+    static constexpr int PMIN = -(LH / 2), PMAX = (3 + LH) / 2, NPQ = PMAX - PMIN + 1;
+    static constexpr int fdiv2(int p) { return p >= 0 ? p / 2 : -((-p + 1) / 2); }
+    static constexpr int DFAR = fdiv2(PMAX) > -fdiv2(PMIN) ? fdiv2(PMAX) : -fdiv2(PMIN);   // farthest lane a partial sum travels
+    static_assert(!XSC || (fdiv2(PMAX) <= GL && -fdiv2(PMIN) <= GR), "halo lanes cover the reach of the partial sums");
     static constexpr int NG = TX / 4 + GL + GR + 2 * XH; // lanes per haloed row
     static constexpr int NR = TY + L - 1;                // haloed rows: loaded, x-synthesised, kept in LDS
     static constexpr int RPW = 64 / NG;                  // rows per wave
@@ -1406,6 +1452,8 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
         v4 raw[DEPTH][NRND][8];    // 4 x of every band of this lane's row(s); DEPTH 2: the set index is the plane's parity
         unsigned off[NRND][NE];    // BYTE offsets inside a plane (kNoRow: this lane holds no row and loads nothing)
         v2 P[NYI][2];              // y-synthesised (x0, x1) pairs of the newest plane: z-low / z-high inputs of the z stage
+        v2 xq[XSC ? NPQ : 1];      // scatter x stage: partial sums of the output pairs PMIN .. PMAX of one stream (short-lived)
+        v2 xo[XSC ? 2 : 1][2];     // scatter x stage: the lane's two output pairs of the z-low / z-high stream of a y-bit
         unsigned ooff[NYI];        // byte offset of this thread's output pair inside a plane
         int ostore[NYI];           // outputs this thread stores: 0 none (outside the volume), 1 the first x only, 2 the pair
     };
@@ -1423,6 +1471,12 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
         asm volatile("" : "+s"(t));
 #endif
         return t;
+    }
+    static NDWT_DEV v2 pinned_v(v2 v) {
+#ifndef NDWT_HOST_EMU
+        asm volatile("" : "+v"(v));
+#endif
+        return v;
     }
     static NDWT_DEV void load_taps(RegTaps& rt, const Taps& tp) {
         if constexpr (EW == 1) {
@@ -1646,6 +1700,99 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
         NDWT_SEND
     }
 
+    // first = true: acc = ..., else acc += ... (the x tap pair K of sample half H, low- or high-pass)
+    template <int H, int K, bool HIGH, bool FIRST> static NDWT_DEV void xtap_first(v2& acc, const v2 w, const RegTaps& tp) {
+        if constexpr (!FIRST) xtap<H, K, HIGH>(acc, w, tp);
+        else if constexpr (!HIGH) PkF32::mul_bt<H, false, false, false>(acc, w, tp.xp[K]);
+        else PkF32::mul_bt<H, true, K % 2 == 0, K % 2 != 0>(acc, w, tp.xp[L - K]);
+    }
+    static constexpr bool xsc_has(int P) { return P >= PMIN && P <= PMAX; }
+    // x stage in scatter form (XSC).  Runs at workgroup level: the partial sums of the neighbouring lanes are read between its passes
+    // (one straight line of code on the GPU; the host emulation finishes a pass for every lane before the next one reads them).
+    template <int SET, class Exec>
+    static NDWT_DEV void xsyn_scatter(Exec& ex, Shared& sh, const RegTaps& tp, int buf) {
+        NDWT_SFOR(k, NRND)
+            NDWT_SFOR(yb, 2)
+                NDWT_SFOR(zb, 2)
+                    // pass 1: the lane's 4 samples of the x-low and the x-high band times every tap pair they reach
+                    ex.each([&](int, State& st) __attribute__((always_inline)) {
+                        NDWT_SFOR(pi, NPQ)
+                            constexpr int P = PMIN + pi;
+                            NDWT_SFOR(xb, 2)
+                                const v4 r = st.raw[SET][k][xb + 2 * yb + 4 * zb];
+                                const v2 w01 = {r[0], r[1]}, w23 = {r[2], r[3]};
+                                NDWT_SFOR(c, 4)
+                                    constexpr int K = c + LH - 2 * P;
+                                    if constexpr (K >= 0 && K <= L) {
+                                        // the first valid (xb, c) of this pair starts the sum
+                                        constexpr int c_first = (2 * P - LH) > 0 ? (2 * P - LH) : 0;
+                                        constexpr bool first = xb == 0 && c == c_first;
+                                        xtap_first<c % 2, K, xb == 1, first>(st.xq[pi], c < 2 ? w01 : w23, tp);
+                                    }
+                                NDWT_SEND
+                            NDWT_SEND
+                        NDWT_SEND
+                    });
+                    // passes 2 ..: sums that travel more than one lane are added to the next-nearer lane's sum for the same destination
+                    NDWT_SFOR(hh, (DFAR > 1 ? DFAR - 1 : 0))
+                        constexpr int h = DFAR - hh;     // DFAR .. 2
+                        ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+                            (void)tid;
+                            NDWT_SFOR(q, 2)
+                                if constexpr (xsc_has(2 * h + q)) {          // to the right: lane i takes lane i-1's
+                                    constexpr int far = 2 * h + q - PMIN, near = 2 * (h - 1) + q - PMIN;
+                                    st.xq[near].x += NDWT_LANE_SHIFT(ex, tid, -1, s.xq[far].x);
+                                    st.xq[near].y += NDWT_LANE_SHIFT(ex, tid, -1, s.xq[far].y);
+                                }
+                                if constexpr (xsc_has(-2 * h + q)) {         // to the left: lane i takes lane i+1's
+                                    constexpr int far = -2 * h + q - PMIN, near = -2 * (h - 1) + q - PMIN;
+                                    st.xq[near].x += NDWT_LANE_SHIFT(ex, tid, 1, s.xq[far].x);
+                                    st.xq[near].y += NDWT_LANE_SHIFT(ex, tid, 1, s.xq[far].y);
+                                }
+                            NDWT_SEND
+                        });
+                    NDWT_SEND
+                    // last pass: own sums + the left neighbour's sums for this lane + the right neighbour's
+                    ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+                        (void)tid;
+                        NDWT_SFOR(q, 2)
+                            v2 o = st.xq[q - PMIN];
+                            if constexpr (xsc_has(2 + q)) {
+                                o.x += NDWT_LANE_SHIFT(ex, tid, -1, s.xq[2 + q - PMIN].x);
+                                o.y += NDWT_LANE_SHIFT(ex, tid, -1, s.xq[2 + q - PMIN].y);
+                            }
+                            if constexpr (xsc_has(-2 + q)) {
+                                o.x += NDWT_LANE_SHIFT(ex, tid, 1, s.xq[-2 + q - PMIN].x);
+                                o.y += NDWT_LANE_SHIFT(ex, tid, 1, s.xq[-2 + q - PMIN].y);
+                            }
+                            // (the sums are only stored under the lane's `valid` test below: without this the compiler sinks the two adds into
+                            // that branch, away from their wave shifts, and the shifts stay v_mov_b32_dpp + v_add_f32 instead of v_add_f32_dpp)
+                            st.xo[zb][q] = pinned_v(o);
+                        NDWT_SEND
+                    });
+                NDWT_SEND
+                ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+                    int ug, r;
+                    bool valid;
+                    lane_item(tid, k, ug, r, valid);
+                    if (valid && ug >= GL + XH && ug < GL + XH + TX / 4) {
+                        const chunk c0 = {st.xo[0][0].x, st.xo[0][0].y, st.xo[1][0].x, st.xo[1][0].y};
+                        const chunk c1 = {st.xo[0][1].x, st.xo[0][1].y, st.xo[1][1].x, st.xo[1][1].y};
+                        chunk* row = sh.xs[buf][yb][r];
+                        row[LD::S(2 * (ug - GL - XH))] = c0;
+                        row[LD::S(2 * (ug - GL - XH) + 1)] = c1;
+                    }
+                });
+            NDWT_SEND
+        NDWT_SEND
+    }
+    // the x stage of register set SET into xs[buf], in the form this instance uses
+    template <int SET, class Exec>
+    static NDWT_DEV void xstage(Exec& ex, Shared& sh, const RegTaps& tp, int buf) {
+        if constexpr (XSC) xsyn_scatter<SET>(ex, sh, tp, buf);
+        else ex.each([&](int tid, State& st) __attribute__((always_inline)) { xsyn<SET>(ex, st, sh, tp, buf, tid); });
+    }
+
     // y-synthesis of output row q from LDS rows q .. q+L-1: the (x0, x1) pairs of the z-low / z-high inputs of the z-synthesis.
     // Kept apart from the z stage so that it exists once, not once per rotation of the z window.
     static NDWT_DEV void ysyn(State& st, Shared& sh, const RegTaps& tp, int buf, int tid) {
@@ -1759,8 +1906,8 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
         RegTaps tp;
         load_taps(tp, tpm);
         const TileCoord tc = decode_tile(a, bid, TX, TY, VEC4 ? -1 : 4 * (GL + XH), 4 * (GR + XH));
-        const long long ibase = batch_base(tc.batch, a.bsplit, a.in_bstride, a.in_bstride2);
-        const long long obase = batch_base(tc.batch, a.bsplit, a.out_bstride, a.out_bstride2);
+        const long long ibase = uniform_ll(batch_base(tc.batch, a.bsplit, a.in_bstride, a.in_bstride2));
+        const long long obase = uniform_ll(batch_base(tc.batch, a.bsplit, a.out_bstride, a.out_bstride2));
         const int zsh = tc.batch * a.zbs;
         const int nsteps = tc.zend - tc.zbeg;
         const int nplanes = nsteps + L - 1;              // planes zbeg-LH .. zend-1+RH
@@ -1810,7 +1957,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
                 const int p = p0 + i;
                 NDWT_TL(0)
                 ex.each([&](int, State& st) __attribute__((always_inline)) { shrink_raw<0>(st, a); });
-                ex.each([&](int tid, State& st) __attribute__((always_inline)) { xsyn<0>(ex, st, sh, tp, i & 1, tid); });
+                xstage<0>(ex, sh, tp, i & 1);
                 NDWT_TL(1)
                 ex.each([&](int, State& st) __attribute__((always_inline)) {
                     if (i + 1 < np) load_raw<0>(st, a, ibase, zb0 + i + 1, zsh);
@@ -1836,7 +1983,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
                 yz(p, Q);
                 if (i + 1 < np) {
                     ex.each([&](int, State& st) __attribute__((always_inline)) { shrink_raw<1 - Q>(st, a); });
-                    ex.each([&](int tid, State& st) __attribute__((always_inline)) { xsyn<1 - Q>(ex, st, sh, tp, 1 - Q, tid); });
+                    xstage<1 - Q>(ex, sh, tp, 1 - Q);
                     NDWT_TL(2)
                     ex.each([&](int tid, State& st) __attribute__((always_inline)) {
                         if (!early_refill(tid) && i + 3 < np) load_raw<1 - Q>(st, a, ibase, zb0 + i + 3, zsh);
@@ -1847,7 +1994,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
             };
             // prologue: x stage of plane 0; the late waves refill its set with plane 2 (the early ones at the start of iteration 0)
             ex.each([&](int, State& st) __attribute__((always_inline)) { shrink_raw<0>(st, a); });
-            ex.each([&](int tid, State& st) __attribute__((always_inline)) { xsyn<0>(ex, st, sh, tp, 0, tid); });
+            xstage<0>(ex, sh, tp, 0);
             ex.each([&](int tid, State& st) __attribute__((always_inline)) {
                 if (!early_refill(tid) && 2 < np) load_raw<0>(st, a, ibase, zb0 + 2, zsh);
             });

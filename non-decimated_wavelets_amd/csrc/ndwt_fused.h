@@ -27,6 +27,8 @@ int launch_inv3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4,
 // float synthesis of real data with tap stride 1, tap lengths <= 8: the pair-packed kernel (Inv3Y) on a 64 x 32 tile with 1024
 // threads; depth = register sets of band loads (2: staggered refill, aligned volumes only)
 int launch_inv3y_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, const void* taps_dev, hipStream_t s, int uniform_yz = 0);
+// the same kernel with its x stage in scatter form (rows of whole groups of 4, two register sets); -1: no instance for this tap length
+int launch_inv3ys_f32(const Fused3Args<float>& a, int Lp, int depth, const void* taps_dev, hipStream_t s, int uniform_yz);
 int launch_inv3yc_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, const void* taps_dev, hipStream_t s);   // interleaved complex
 int launch_inv3y4_f32(const Fused3Args<float>& a, int Lp, int depth, const void* taps_dev, hipStream_t s);   // a level dilated by 4 (EW = 4), vec4 rows
 

@@ -20,6 +20,7 @@ int emu_y_small2(int Lp, int vec4, ndwt::Fused3Args<float>& a, const double* lo,
 int emu_y_prod(int depth, int Lp, int vec4, ndwt::Fused3Args<float>& a, const double* lo, const double* hi);
 int emu_yc_small(int depth, int Lp, int vec4, ndwt::Fused3Args<float>& a, const double* lo, const double* hi);
 int emu_y_dilated(int ew, int depth, int Lp, ndwt::Fused3Args<float>& a, const double* lo, const double* hi);
+int emu_y_scatter(int small, int Lp, ndwt::Fused3Args<float>& a, const double* lo, const double* hi);
 
 namespace {
 
@@ -213,6 +214,11 @@ int emu3(int Lp, int vec4, const T* in, T* out, int n1, int n2, int n3, int nbat
         }
     }
     if constexpr (INV && sizeof(T) == 4) {   // pair-packed synthesis (Inv3Y): variant 5 one register set of band loads, 8 two (staggered refill)
+        if (variant == 10 && vec4) {            // its x stage in scatter form (XSC): the library's default for 10 .. 20 taps
+            if (small_tile) geometry(16, 8);
+            else geometry(ndwt::inv3y_tx(Lp), ndwt::inv3y_ty(Lp));
+            return emu_y_scatter(small_tile ? 1 : 0, Lp, a, lo, hi);
+        }
         if (variant == 5 || variant == 8) {
             if (small_tile) {
                 geometry(16, 8);
@@ -438,6 +444,32 @@ int emu_y_prod(int depth, int Lp, int vec4, ndwt::Fused3Args<float>& a, const do
     if (uni && Lp == 12) return runY<ndwt::Inv3Y<float, 12, ndwt::kInv3YTX, ndwt::kInv3YTY, 1024, true, 2, 2, 1, ndwt::inv3y_zlds(12, 2), 0, true>, float>(a, lo, hi);
     return depth == 1 ? dispatchY<float, ndwt::kInv3YTX, ndwt::kInv3YTY, 1024, false, 1>(Lp, vec4, a, lo, hi)
                       : dispatchY<float, ndwt::kInv3YTX, ndwt::kInv3YTY, 1024, false, 2>(Lp, vec4, a, lo, hi);
+}
+#endif
+#if EMU_IN(17)
+// Inv3Y with the x stage in scatter form: the small test tile for every tap length (partial sums that travel 1, 2 and 3 lanes), the
+// production instances of the library (ndwt_fused3_f32_invys.hip) for 8 / 12 / 20 taps
+template <int LL, int TX, int TY, int NT, int DEPTH, int ZLV, bool UNI> static int run_ys(ndwt::Fused3Args<float>& a, const double* lo, const double* hi) {
+    return runY<ndwt::Inv3Y<float, LL, TX, TY, NT, true, 2, DEPTH, 1, ZLV, 0, UNI, true>, float>(a, lo, hi);
+}
+int emu_y_scatter(int small, int Lp, ndwt::Fused3Args<float>& a, const double* lo, const double* hi) {
+    bool uni = true;
+    for (int j = 0; j < Lp; ++j) uni = uni && lo[1 * ndwt::kMaxTaps + j] == lo[2 * ndwt::kMaxTaps + j];
+    if (small) {
+#define CASES(LL) case LL: return run_ys<LL, 16, 8, 512, 2, (LL >= 4 ? LL / 2 : 0), false>(a, lo, hi);
+        switch (Lp) {
+            CASES(2) CASES(4) CASES(6) CASES(8) CASES(10) CASES(12) CASES(14) CASES(16) CASES(18) CASES(20)
+            default: return -1;
+        }
+#undef CASES
+    }
+    switch (Lp) {
+        case 8: return run_ys<8, ndwt::inv3y_tx(8), ndwt::inv3y_ty(8), 1024, 2, ndwt::inv3y_zlds(8, 2), false>(a, lo, hi);
+        case 12: return uni ? run_ys<12, ndwt::inv3y_tx(12), ndwt::inv3y_ty(12), 1024, 2, ndwt::inv3y_zlds(12, 2), true>(a, lo, hi)
+                            : run_ys<12, ndwt::inv3y_tx(12), ndwt::inv3y_ty(12), 1024, 2, ndwt::inv3y_zlds(12, 2), false>(a, lo, hi);
+        case 20: return run_ys<20, ndwt::inv3y_tx(20), ndwt::inv3y_ty(20), 1024, 1, ndwt::inv3y_zlds(20, 1), true>(a, lo, hi);
+        default: return -1;
+    }
 }
 #endif
 #if EMU_IN(12)

@@ -175,6 +175,49 @@ def test_emulated_pair_packed_synthesis_of_a_zero_extended_slab(emu, sizes, wn, 
         assert np.abs(got - want).max() <= 2e-6 * max(np.abs(want).max(), 1.0), variant
 
 
+@pytest.mark.slow
+@pytest.mark.parametrize("sizes,wn,zchunk,small", [
+    ((16, 9, 7), ("db1", "db3", "db1"), 0, True),
+    ((20, 17, 12), ("db4", "db4", "db4"), 5, True),               # partial sums travel one lane
+    ((24, 19, 11), ("db6", "db2", "db4"), 0, True),               # ... two lanes (12 taps), mixed tap lengths padded to 12
+    ((24, 21, 13), ("db5", "db5", "db5"), 0, True),
+    ((24, 23, 19), ("db7", "db7", "db7"), 0, True),
+    ((28, 20, 21), ("db8", "db8", "db4"), 7, True),
+    ((20, 26, 20), ("db9", "db9", "db9"), 0, True),               # ... three lanes to the right (18 taps)
+    ((24, 22, 21), ("db10", "db10", "db10"), 0, True),            # ... three lanes both ways (20 taps)
+    ((68, 39, 9), ("db4", "db4", "db4"), 0, False),               # the library's instances on their production tiles: 8 taps,
+    ((72, 37, 12), ("db6", "db6", "db6"), 0, False),              # 12 taps with the shared y / z tap pairs,
+    ((72, 37, 12), ("db6", "db6", "db4"), 4, False),              # 12 taps, y and z taps apart,
+    ((52, 30, 9), ("db10", "db10", "db10"), 0, False),            # 20 taps on the 48 x 28 tile
+])
+def test_emulated_pair_packed_synthesis_scatter_x_stage(emu, sizes, wn, zchunk, small):
+    """Inv3Y<..., XSC>: the x stage in scatter form (partial sums travel between lanes instead of samples; the library's default for
+    10 .. 20 taps on rows of whole groups of 4) -- periodic levels and one zero-extended slab per case"""
+    rng = np.random.default_rng(33)
+    c = rng.standard_normal(tuple(sizes) + (8,))
+    filt = [orc.wave_filters(w) for w in wn]
+    for l2 in (0, 1):
+        want = orc.spatial_level_rec(c, filt, l2)
+        got = _run(emu, c, wn, l2, True, np.float32, True, zchunk, small, variant=10)
+        assert np.isfinite(got).all()
+        assert np.abs(got - want).max() <= 2e-6 * max(np.abs(want).max(), 1.0)
+    # zero-extended slab (the scatter-add synthesis of the sharded drivers), as in the test above
+    n1, n2, n_in = sizes
+    L = max(len(f[0]) for f in filt)
+    pad = L - 1
+    cp = np.zeros((n1, n2, n_in + 2 * pad, 8))
+    cp[:, :, pad:pad + n_in] = c
+    ftz = [filt[0], filt[1], (np.pad(filt[2][0], ((L - len(filt[2][0])) // 2,) * 2), np.pad(filt[2][1], ((L - len(filt[2][1])) // 2,) * 2))]
+    full = orc.spatial_level_rec(cp, ftz, 1)
+    sa = L // 2 - 1
+    want = full[:, :, pad - sa:pad - sa + n_in + L - 1]
+    src = np.full((n1, n2, n_in + L - 1, 8), np.nan)
+    src[:, :, :n_in] = c
+    got = _run(emu, src, wn, 1, True, np.float32, True, zchunk, small, z_wrap=3, variant=10)
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= 2e-6 * max(np.abs(want).max(), 1.0)
+
+
 CASES_YC = [
     ((10, 9, 7), ("db1", "db3", "db1"), True, 0),
     ((12, 10, 9), ("db2", "db2", "db2"), False, 4),
