@@ -540,6 +540,31 @@ def test_long_filters_float(sizes, wn, path):
     assert _relerr(w.rec(y).cpu().numpy(), x) < 1e-5
 
 
+@pytest.mark.parametrize("sizes,wn", [
+    ([64, 40, 36], "db4"),                                             # 8 taps: the gather form is the default, the scatter form on request (10)
+    ([128, 64, 40], "db5"), ([64, 40, 36], "db6"), ([72, 36, 30], ["db6", "db6", "db4"]),   # 10 / 12 taps, with and without the shared y / z tap pairs
+    ([64, 40, 36], "db8"), ([64, 48, 32], "db9"), ([96, 56, 30], "db10"),                   # sums that travel 2 and 3 lanes; the 64 x 24 and 48 x 28 tiles
+])
+def test_scatter_and_gather_form_of_the_synthesis_x_stage(sizes, wn):
+    """Inv3Y's x stage in scatter form (partial sums travel between lanes; default for 10 .. 20 taps on rows of whole groups of 4) and in
+    gather form (variant_inv 11; variant_inv 10 = scatter form for 8 taps too): both against the oracle, and against each other to rounding"""
+    rng = np.random.default_rng(41)
+    wl = [wn] * 3 if isinstance(wn, str) else wn
+    c = rng.standard_normal(sizes + [15])
+    cg = _colmajor_gpu(c, "single")
+    want = orc.spatial_rec(c, wl, 1)
+    scale = max(np.abs(want).max(), np.abs(c).max())
+    got = {}
+    for variant in (10, 11):
+        w = ndwt.nd_dwt_3D(wn, sizes, "pres_l2_norm", 1, "precision", "single")
+        w._plan(False, 2, cg.device).set_variant(inv=variant)
+        got[variant] = w.rec(cg).cpu().numpy()
+        assert list(w._plans.values())[0].describe() == "fused3d"
+        assert np.abs(got[variant] - want).max() <= TOL["single"] * scale, variant
+    assert np.abs(got[10] - got[11]).max() <= 1e-6 * scale
+    assert np.abs(got[10] - got[11]).max() > 0                         # two different kernels did run
+
+
 @pytest.mark.parametrize("sizes,wn,path", [
     ([64, 40, 36], "db7", "fused3d"),                                  # 14 taps: 64 x 8 tiles, 512 threads
     ([68, 41, 30], "db8", "fused3d"),                                  # 16 taps, ragged tiles
