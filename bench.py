@@ -191,8 +191,15 @@ def measure_config(api, torch, dev, d, sizes, wname, level, steps, warmup):
         plan.dec(x.data_ptr(), y.data_ptr(), level, stream)
         plan.rec(y.data_ptr(), r.data_ptr(), level, stream)
 
-    for _ in range(warmup):
+    # warm-up: `warmup` steps and at least 80 ms of them -- a device that has idled (the allocations above) runs its first ~35 ms of work
+    # at 1.06 - 1.5x the steady time (tools/ramp_profile.py), which is most of a 50-step measurement of cfg2's 0.4-ms step
+    tw = time.perf_counter()
+    done = 0
+    while done < warmup or time.perf_counter() - tw < 0.08:
         step()
+        done += 1
+        if done % 8 == 0:
+            torch.cuda.synchronize(dev)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -412,14 +419,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(a.warmup):
-        step()
     # The interpreter's cyclic garbage collector is kept out of the timed regions: a full collection walks every object torch has created
     # (38 ms measured) and, landing in a 20-step loop of 0.9-ms steps of the sharded driver, doubles the figure (tools/host_overhead_nccl.py).
-    # Everything alive now is moved to the permanent generation; what the steps allocate is still collected, cheaply.
+    # Everything alive now is moved to the permanent generation; what the steps allocate is still collected, cheaply.  This happens BEFORE the
+    # warm-up: the collection is 40 ms of host time with an idle device, and a device that has idled runs its next step at 1.5x and the
+    # four after it at 1.06x the steady time (tools/ramp_profile.py) -- between the warm-up and the timed region it undid the warm-up
+    # (20 timed steps: 5.80 ms per step against 5.58 ms over 500).
     import gc
     gc.collect()
     gc.freeze()
+    for _ in range(a.warmup):
+        step()
     # ---- timed region: exactly a.steps steps, no per-kernel event recording inside it ----
     fence()
     t0 = time.perf_counter()
