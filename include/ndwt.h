@@ -259,6 +259,9 @@ int ndwt_mplan_set_exchange(ndwt_mplan* plan, int exchange);
  * sums staged through the receive buffers even between slabs that share a device -- how the tests run that path on one GPU.) */
 int ndwt_mplan_set_overlap(ndwt_mplan* plan, int overlap);
 int ndwt_mplan_describe(const ndwt_mplan* plan, char* buf, int buflen);   /* slabs, exchange schemes, peer-access findings */
+/* diagnostic: host microseconds the last ndwt_mdec / ndwt_mrec spent QUEUEING work for all slabs (one host thread drives every device: with
+ * many devices this, not the devices, can bound a call); -1 without a plan */
+double ndwt_mplan_last_enqueue_us(const ndwt_mplan* plan);
 int ndwt_mdec(ndwt_mplan* plan, const void* const* x_slabs, void* const* y_slabs, int level);
 int ndwt_mrec(ndwt_mplan* plan, const void* const* y_slabs, void* const* x_slabs, int level);
 int ndwt_mdec_host(ndwt_mplan* plan, const void* x_host, void* y_host, int level);

@@ -27,6 +27,7 @@
 //              every band per level) -- bit-identical to one device, and the path of plans whose levels run per-axis kernels.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -79,6 +80,9 @@ struct ndwt_mplan {
     int overlap;                   // copies on the slabs' copy streams, overlapped with the launches that do not wait for them
     std::vector<Slab> slabs;
     std::string notes;             // peer-access findings of plan creation (ndwt_mplan_describe)
+    double last_enqueue_us;        // host time the last ndwt_mdec / ndwt_mrec spent queueing work (before it waited for the devices)
+    std::vector<std::vector<int>> nbr;   // nbr[i]: the slabs (i itself included) that own a plane within halo_max of slab i: the only slabs whose
+                                         // buffers slab i ever reads or whose copies ever read slab i's (the relation is symmetric)
 };
 
 static thread_local std::string g_merr;
@@ -155,17 +159,23 @@ static int add_planes(ndwt_mplan* mp, Slab& s, char* dst, const char* src, long 
     return NDWT_OK;
 }
 
-// every stream waits for every slab's ready[k]: the level barrier between slabs (events only, the host does not block)
+// The level barrier between slabs (events only, the host does not block): every stream waits for ready[k] of the slabs within halo reach of
+// its own -- the slabs whose approximation planes its next level copies (read after write) and whose copies read the buffer its level after
+// next overwrites (write after read).  Slabs further away are ordered through those (a slab records ready[k] behind its waits of the level
+// before).  With all G slabs waiting for all G (2 G^2 calls per level) this function was two thirds of the calls of a transform on 8 devices.
 static int level_barrier(ndwt_mplan* mp, int k) {
     for (auto& s : mp->slabs) {
         MHIP(hipSetDevice(s.device));
         MHIP(hipEventRecord(s.ready[k], s.stream));
     }
-    for (auto& s : mp->slabs)
-        for (auto& o : mp->slabs) {
+    for (size_t i = 0; i < mp->slabs.size(); ++i) {
+        Slab& s = mp->slabs[i];
+        for (int j : mp->nbr[i]) {
+            Slab& o = mp->slabs[(size_t)j];
             if (&o != &s) MHIP(hipStreamWaitEvent(s.stream, o.ready[k], 0));
             MHIP(hipStreamWaitEvent(s.cstream, o.ready[k], 0));   // (its own slab's too: the copy stream is ordered by events only)
         }
+    }
     return NDWT_OK;
 }
 
@@ -454,6 +464,17 @@ int ndwt_mplan_create(ndwt_mplan** out, int ndim, const int64_t* dims, const cha
         s.n = (long long)(i + 1) * N / ndev - s.z0;
         mp->slabs.push_back(s);
     }
+    mp->nbr.resize(mp->slabs.size());
+    for (size_t i = 0; i < mp->slabs.size(); ++i) {
+        const Slab& si = mp->slabs[i];
+        for (long long d = -mp->halo_max; d < si.n + mp->halo_max; ++d) {
+            const Slab* o = owner_of(mp, ((si.z0 + d) % N + N) % N);
+            const int j = o ? (int)(o - &mp->slabs[0]) : (int)i;
+            bool have = false;
+            for (int q : mp->nbr[i]) have = have || q == j;
+            if (!have) mp->nbr[i].push_back(j);
+        }
+    }
     int rc = NDWT_OK;
     mp->fast = 1;
     for (auto& s : mp->slabs) {
@@ -540,6 +561,8 @@ int ndwt_mplan_set_overlap(ndwt_mplan* mp, int overlap) {
     return NDWT_OK;
 }
 
+double ndwt_mplan_last_enqueue_us(const ndwt_mplan* mp) { return mp ? mp->last_enqueue_us : -1.0; }
+
 int ndwt_mplan_describe(const ndwt_mplan* mp, char* buf, int buflen) {
     if (!mp || !buf || buflen < 1) return mfail(NDWT_ERR_INVALID_ARG, "bad arguments");
     const bool scatter = mp->exchange == NDWT_EXCHANGE_SCATTER && mp->fast && mp->dilation == NDWT_DILATION_REFERENCE;
@@ -559,7 +582,9 @@ int ndwt_mdec(ndwt_mplan* mp, const void* const* x_slabs, void* const* y_slabs, 
     if (!x_slabs || !y_slabs) return mfail(NDWT_ERR_INVALID_ARG, "null pointer array");
     for (size_t i = 0; i < mp->slabs.size(); ++i)
         if (!x_slabs[i] || !y_slabs[i]) return mfail(NDWT_ERR_INVALID_ARG, "null slab pointer %zu", i);
+    const auto t0 = std::chrono::steady_clock::now();
     rc = mdec_core(mp, x_slabs, y_slabs, level);
+    mp->last_enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     const int rs = sync_all(mp);                          // (also after an error: nothing stays queued on buffers the caller owns)
     return rc ? rc : rs;
 }
@@ -570,7 +595,9 @@ int ndwt_mrec(ndwt_mplan* mp, const void* const* y_slabs, void* const* x_slabs, 
     if (!x_slabs || !y_slabs) return mfail(NDWT_ERR_INVALID_ARG, "null pointer array");
     for (size_t i = 0; i < mp->slabs.size(); ++i)
         if (!x_slabs[i] || !y_slabs[i]) return mfail(NDWT_ERR_INVALID_ARG, "null slab pointer %zu", i);
+    const auto t0 = std::chrono::steady_clock::now();
     rc = mrec_core(mp, y_slabs, x_slabs, level);
+    mp->last_enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     const int rs = sync_all(mp);
     return rc ? rc : rs;
 }

@@ -1,0 +1,33 @@
+"""Host time of the single-process multi-device plan (ndwt_mplan_*: ONE host thread queues the work of every slab): how long ndwt_mdec / ndwt_mrec
+take to QUEUE a call for G slabs (all on device 0 here), next to what one device of a G-GPU run would compute.  If the queueing takes longer
+than one device's share of the compute, a real G-GPU run is bound by the host thread.  python tools/mplan_host_time.py [G] [wname] [level]"""
+import importlib
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+api = importlib.import_module("non-decimated_wavelets_amd.api")
+L = importlib.import_module("non-decimated_wavelets_amd._lib")
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+wname = sys.argv[2] if len(sys.argv) > 2 else "db4"
+level = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+n = 512
+for overlap in (True, False):
+    mp = api.MultiPlan([n, n, n], [wname] * 3, torch.float32, [0] * G, pres_l2_norm=True, max_level=level).set_overlap(overlap)
+    xs = [torch.randn(nz, n, n, device="cuda") for (_, _, nz) in mp.slabs()]
+    ys = mp.dec_device(xs, level)
+    rs = mp.rec_device(ys)
+    reps, qd, qr, wall = 20, 0.0, 0.0, 0.0
+    for i in range(reps):
+        t0 = time.perf_counter()
+        ys = mp.dec_device(xs, level)
+        qd += L.lib().ndwt_mplan_last_enqueue_us(mp._h)
+        rs = mp.rec_device(ys)
+        qr += L.lib().ndwt_mplan_last_enqueue_us(mp._h)
+        wall += time.perf_counter() - t0
+    err = max(float((r - x).abs().max()) for r, x in zip(rs, xs))
+    print(f"{G} slabs on one GPU, {wname} {level} levels, overlap={overlap}: queueing dec {qd / reps:7.1f} us + rec {qr / reps:7.1f} us per call; "
+          f"wall {wall / reps * 1e3:6.2f} ms per dec+rec (all slabs on ONE device: /{G} = {wall / reps * 1e3 / G:5.2f} ms per device); max |rec - x| {err:.1e}")
+    del mp, xs, ys, rs
