@@ -259,6 +259,11 @@ int ndwt_mplan_set_exchange(ndwt_mplan* plan, int exchange);
  * sums staged through the receive buffers even between slabs that share a device -- how the tests run that path on one GPU.) */
 int ndwt_mplan_set_overlap(ndwt_mplan* plan, int overlap);
 int ndwt_mplan_describe(const ndwt_mplan* plan, char* buf, int buflen);   /* slabs, exchange schemes, peer-access findings */
+/* 1 (default with more than one slab): one host thread per slab queues that slab's work (persistent workers of the plan: asleep between
+ * calls; the calling thread drives slab 0 and returns when every device has finished, as before); 0: the calling thread queues everything.
+ * Same work on the same streams in the same per-stream order: identical results.  Queueing a 512^3 db4 dec + rec for 8 slabs from one
+ * thread takes 1.7 ms of host time -- more than one of 8 devices needs to compute its share. */
+int ndwt_mplan_set_threads(ndwt_mplan* plan, int threads);
 /* diagnostic: host microseconds the last ndwt_mdec / ndwt_mrec spent QUEUEING work for all slabs (one host thread drives every device: with
  * many devices this, not the devices, can bound a call); -1 without a plan */
 double ndwt_mplan_last_enqueue_us(const ndwt_mplan* plan);

@@ -28,7 +28,7 @@ EXPORTS = [
     "ndwt_synthesis_level_slab_part", "ndwt_analysis_level_slab_runs", "ndwt_synthesis_level_slab_runs", "ndwt_last_error",
     "ndwt_version", "ndwt_mplan_create", "ndwt_mplan_destroy", "ndwt_mplan_num_slabs", "ndwt_mplan_slab", "ndwt_mdec_host",
     "ndwt_mrec_host", "ndwt_mplan_last_error", "ndwt_mdec", "ndwt_mrec", "ndwt_mplan_set_exchange", "ndwt_mplan_describe", "ndwt_plan_slab_fast", "ndwt_dec_pitched", "ndwt_rec_pitched", "ndwt_shrink_pitched", "ndwt_band_pitch", "ndwt_slab_segments",
-    "ndwt_plan_release_staging", "ndwt_mplan_set_overlap", "ndwt_mplan_last_enqueue_us", "ndwt_comm_unique_id", "ndwt_comm_create", "ndwt_comm_destroy", "ndwt_comm_exchange",
+    "ndwt_plan_release_staging", "ndwt_mplan_set_overlap", "ndwt_mplan_last_enqueue_us", "ndwt_mplan_set_threads", "ndwt_comm_unique_id", "ndwt_comm_create", "ndwt_comm_destroy", "ndwt_comm_exchange",
     "ndwt_comm_last_error", "ndwt_coef_create", "ndwt_coef_release", "ndwt_coef_info", "ndwt_coef_dec_host", "ndwt_coef_rec_host",
     "ndwt_coef_shrink", "ndwt_coef_get_host", "ndwt_coef_put_host",
 ]
@@ -127,6 +127,7 @@ def lib() -> ctypes.CDLL:
         f.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]
     L.ndwt_mplan_set_exchange.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.ndwt_mplan_set_overlap.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.ndwt_mplan_set_threads.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.ndwt_mplan_last_enqueue_us.argtypes = [ctypes.c_void_p]
     L.ndwt_mplan_last_enqueue_us.restype = ctypes.c_double
     L.ndwt_mplan_describe.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]

@@ -310,6 +310,11 @@ class MultiPlan:
         L.mcheck(L.lib().ndwt_mplan_set_overlap(self._h, int(on)))
         return self
 
+    def set_threads(self, on):
+        """True (default): one host thread per slab queues that slab's work; False: the calling thread queues everything.  Same results."""
+        L.mcheck(L.lib().ndwt_mplan_set_threads(self._h, int(bool(on))))
+        return self
+
     def describe(self) -> str:
         buf = ctypes.create_string_buffer(512)
         L.mcheck(L.lib().ndwt_mplan_describe(self._h, buf, 512))

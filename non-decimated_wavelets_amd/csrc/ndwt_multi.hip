@@ -27,11 +27,16 @@
 //              every band per level) -- bit-identical to one device, and the path of plans whose levels run per-axis kernels.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ndwt.h"
@@ -68,6 +73,24 @@ __global__ __launch_bounds__(256) void add_planes_kernel(T* __restrict__ dst, co
 
 }  // namespace
 
+// The host side of a call with several slabs: one thread per slab queues that slab's work (ONE thread queueing for 8 devices takes longer
+// than a device needs to compute its share: 1.7 ms against 1.0 ms for cfg3 -- tools/mplan_host_time.py).  Slab 0 is the caller; the others
+// are persistent workers that sleep between calls and spin between the phases of one (a phase = the same function for every slab, all
+// slabs done before the next phase starts: what one slab's stream waits for must have been RECORDED by the host before the wait is queued).
+struct Team {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv;
+    bool stop = false;
+    int call_gen = 0;                     // (under m) a call has begun: workers wake up and spin on phase_gen
+    std::atomic<int> active{0};           // a call is in progress
+    std::atomic<int> phase_gen{0};
+    std::atomic<int> remaining{0};
+    std::function<int(size_t)> job;
+    std::vector<int> rc;
+    std::vector<std::string> err;
+};
+
 struct ndwt_mplan {
     int ndim, dtype, complexity, max_level, nb;
     long long dims[NDWT_MAX_DIMS];
@@ -81,6 +104,8 @@ struct ndwt_mplan {
     std::vector<Slab> slabs;
     std::string notes;             // peer-access findings of plan creation (ndwt_mplan_describe)
     double last_enqueue_us;        // host time the last ndwt_mdec / ndwt_mrec spent queueing work (before it waited for the devices)
+    int threads;                   // 1: one host thread per slab queues its work (default with more than one slab); 0: the caller queues everything
+    Team* team;
     std::vector<std::vector<int>> nbr;   // nbr[i]: the slabs (i itself included) that own a plane within halo_max of slab i: the only slabs whose
                                          // buffers slab i ever reads or whose copies ever read slab i's (the relation is symmetric)
 };
@@ -111,6 +136,90 @@ static int mfail(int code, const char* fmt, ...) {
         int rc_ = (expr);                   \
         if (rc_ != NDWT_OK) return rc_;     \
     } while (0)
+
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
+
+static void team_worker(ndwt_mplan* mp, size_t i) {
+    Team& t = *mp->team;
+    int seen_call = 0, seen_phase = 0;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(t.m);
+            t.cv.wait(lk, [&] { return t.stop || t.call_gen != seen_call; });
+            if (t.stop) return;
+            seen_call = t.call_gen;
+        }
+        while (t.active.load(std::memory_order_acquire)) {
+            const int g = t.phase_gen.load(std::memory_order_acquire);
+            if (g == seen_phase) { cpu_relax(); continue; }
+            seen_phase = g;
+            const int rc = t.job(i);
+            t.rc[i] = rc;
+            if (rc) t.err[i] = g_merr;
+            t.remaining.fetch_sub(1, std::memory_order_release);
+        }
+    }
+}
+
+// a call begins: the workers wake up (created on the first call) and spin until team_end
+static void team_begin(ndwt_mplan* mp) {
+    const size_t G = mp->slabs.size();
+    if (!mp->threads || G < 2) return;
+    if (!mp->team) {
+        mp->team = new Team();
+        mp->team->rc.assign(G, 0);
+        mp->team->err.assign(G, std::string());
+        for (size_t i = 1; i < G; ++i) mp->team->th.emplace_back(team_worker, mp, i);
+    }
+    Team& t = *mp->team;
+    t.active.store(1, std::memory_order_release);
+    {
+        std::lock_guard<std::mutex> lk(t.m);
+        ++t.call_gen;
+    }
+    t.cv.notify_all();
+}
+static void team_end(ndwt_mplan* mp) {
+    if (mp->team) mp->team->active.store(0, std::memory_order_release);
+}
+static void team_destroy(ndwt_mplan* mp) {
+    if (!mp->team) return;
+    {
+        std::lock_guard<std::mutex> lk(mp->team->m);
+        mp->team->stop = true;
+    }
+    mp->team->cv.notify_all();
+    for (auto& th : mp->team->th) th.join();
+    delete mp->team;
+    mp->team = nullptr;
+}
+
+// One phase of a call: fn(i) for every slab i -- concurrently, one host thread per slab, when the team is active; in slab order on the
+// caller's thread otherwise.  Returns when every slab's fn has returned, with the first error (its message in this thread's g_merr).
+// fn(i) touches slab i's streams only, and starts with hipSetDevice (the current device is per thread).
+template <class F> static int phase(ndwt_mplan* mp, F&& fn) {
+    const size_t G = mp->slabs.size();
+    Team* t = mp->team;
+    if (!t || !t->active.load(std::memory_order_relaxed)) {
+        for (size_t i = 0; i < G; ++i) MRET(fn(i));
+        return NDWT_OK;
+    }
+    t->job = [&fn](size_t i) -> int { return fn(i); };
+    t->remaining.store((int)G - 1, std::memory_order_relaxed);
+    t->phase_gen.fetch_add(1, std::memory_order_release);
+    const int rc0 = fn(0);
+    while (t->remaining.load(std::memory_order_acquire) != 0) cpu_relax();
+    if (rc0) return rc0;
+    for (size_t i = 1; i < G; ++i)
+        if (t->rc[i]) { g_merr = t->err[i]; return t->rc[i]; }
+    return NDWT_OK;
+}
 
 static long long stride_of(const ndwt_mplan* mp, int lev) { return mp->dilation == NDWT_DILATION_ATROUS ? (1LL << (lev - 1)) : 1LL; }
 
@@ -163,20 +272,26 @@ static int add_planes(ndwt_mplan* mp, Slab& s, char* dst, const char* src, long 
 // its own -- the slabs whose approximation planes its next level copies (read after write) and whose copies read the buffer its level after
 // next overwrites (write after read).  Slabs further away are ordered through those (a slab records ready[k] behind its waits of the level
 // before).  With all G slabs waiting for all G (2 G^2 calls per level) this function was two thirds of the calls of a transform on 8 devices.
-static int level_barrier(ndwt_mplan* mp, int k) {
-    for (auto& s : mp->slabs) {
-        MHIP(hipSetDevice(s.device));
-        MHIP(hipEventRecord(s.ready[k], s.stream));
-    }
-    for (size_t i = 0; i < mp->slabs.size(); ++i) {
-        Slab& s = mp->slabs[i];
-        for (int j : mp->nbr[i]) {
-            Slab& o = mp->slabs[(size_t)j];
-            if (&o != &s) MHIP(hipStreamWaitEvent(s.stream, o.ready[k], 0));
-            MHIP(hipStreamWaitEvent(s.cstream, o.ready[k], 0));   // (its own slab's too: the copy stream is ordered by events only)
-        }
+// Two phases: every slab's ready[k] is recorded (by the host) before any stream is told to wait for it.
+static int barrier_record(ndwt_mplan* mp, size_t i, int k) {
+    Slab& s = mp->slabs[i];
+    MHIP(hipSetDevice(s.device));
+    MHIP(hipEventRecord(s.ready[k], s.stream));
+    return NDWT_OK;
+}
+static int barrier_wait(ndwt_mplan* mp, size_t i, int k) {
+    Slab& s = mp->slabs[i];
+    MHIP(hipSetDevice(s.device));
+    for (int j : mp->nbr[i]) {
+        Slab& o = mp->slabs[(size_t)j];
+        if (&o != &s) MHIP(hipStreamWaitEvent(s.stream, o.ready[k], 0));
+        MHIP(hipStreamWaitEvent(s.cstream, o.ready[k], 0));   // (its own slab's too: the copy stream is ordered by events only)
     }
     return NDWT_OK;
+}
+static int level_barrier(ndwt_mplan* mp, int k) {
+    MRET(phase(mp, [&](size_t i) { return barrier_record(mp, i, k); }));
+    return phase(mp, [&](size_t i) { return barrier_wait(mp, i, k); });
 }
 
 static int sync_all(ndwt_mplan* mp) {
@@ -223,8 +338,9 @@ static int mdec_core(ndwt_mplan* mp, const void* const* x, void* const* y, int l
         const long long ab = (long long)(mp->L_outer / 2 - 1) * st, aa = (long long)(mp->L_outer / 2) * st;
         // level lev reads approx[rd] (level 1: the caller's x) and writes its approximation into approx[wr] (the last level: band 0 of y)
         const int rd = ((lev - 1) & 1) ^ 1, wr = (lev - 1) & 1;
-        size_t i = 0;
-        for (auto& s : mp->slabs) {
+        // one slab's work of this level (its copies out of the neighbours' buffers, its launches) and the record of its ready[wr]
+        auto body = [&](size_t i) -> int {
+            Slab& s = mp->slabs[i];
             MHIP(hipSetDevice(s.device));
             void* outs[16];
             outs[0] = lev == level ? y[i] : (void*)(s.approx[wr] + (size_t)H * pb);
@@ -277,11 +393,12 @@ static int mdec_core(ndwt_mplan* mp, const void* const* x, void* const* y, int l
                 MRET(copy_planes(mp, s, mid + (size_t)s.n * pb, s.z0 + s.n, aa, src, -1));
                 MTRY(ndwt_analysis_level_slab(s.plan, mid - (size_t)ab * pb, outs, (int)st, s.stream));
             }
-            ++i;
-        }
+            return barrier_record(mp, i, wr);
+        };
+        MRET(phase(mp, body));
         // approx[wr] of every slab is complete, and approx[rd] free to be overwritten by level lev + 1, once every slab's work of this
-        // level (its launch and its halo copies out of the neighbours' buffers) is done
-        MRET(level_barrier(mp, wr));
+        // level (its launch and its halo copies out of the neighbours' buffers) is done: the level barrier's waits
+        MRET(phase(mp, [&](size_t i) { return barrier_wait(mp, i, wr); }));
     }
     return NDWT_OK;
 }
@@ -333,61 +450,67 @@ static int mrec_core(ndwt_mplan* mp, const void* const* y, void* const* x, int l
             // margins first (one launch: two runs of m planes at the ends of the zero-extended result), so that they travel -- on the
             // destinations' copy streams -- while every slab synthesises its own planes; the adds follow that launch in stream order
             const long long m = sa > sb ? sa : sb;
-            size_t i = 0;
-            for (auto& s : mp->slabs) {
+            MRET(phase(mp, [&](size_t i) -> int {
+                Slab& s = mp->slabs[i];
                 MHIP(hipSetDevice(s.device));
                 const void* ins[16];
                 for (int b = 0; b < nb; ++b) ins[b] = band_ptr(i, s, b);
                 MTRY(ndwt_synthesis_level_slab_runs(s.plan, ins, s.n, 0, s.n + sa + sb - m, 2, m, s.mb, 1, s.stream));   // mb: [run 0 | run 1]
                 MHIP(hipEventRecord(s.margins, s.stream));
                 MTRY(ndwt_synthesis_level_slab_part(s.plan, ins, s.n, sa, s.n, dst_of(s), 1, s.stream));
-                s.recv_used = 0;
-                ++i;
-            }
+                return NDWT_OK;
+            }));
             // the partial sums: run 0 holds planes [0, m) of the zero-extended result (the first sa: owed to the planes before the slab),
             // run 1 planes [n + sa + sb - m, n + sa + sb) (the last sb: the planes after it).  Copies to other devices go to the
-            // destination's copy stream and a region of its receive buffer of their own; the adds come in slab order, "before" margins
-            // first, behind the destination's own launch: the same fixed order of summation as without overlap.
-            struct Pending { Slab* to; char* dst; const char* src; long long run; };
-            std::vector<Pending> adds;
+            // destination's copy stream and a region of its receive buffer of their own; the adds come in slab order of the producers,
+            // "before" margins first, behind the destination's own launch: the same fixed order of summation as without overlap.
+            // Every DESTINATION slab queues what arrives at it (its own streams only): the producers' margins events were recorded in the
+            // phase above.  The record of its ready[wr] (level barrier) closes the phase.
             const long long N = mp->dims[mp->ndim - 1];
-            for (auto& from : mp->slabs) {
-                for (int side = 0; side < 2; ++side) {
-                    const long long count = side == 0 ? sa : sb;
-                    const long long g = side == 0 ? from.z0 - sa : from.z0 + from.n;
-                    const char* buf = side == 0 ? from.mb : from.mb + (size_t)(m + (m - sb)) * pb;
-                    long long done = 0;
-                    while (done < count) {
-                        const long long gp = ((g + done) % N + N) % N;
-                        Slab* to = owner_of(mp, gp);
-                        if (!to) return mfail(NDWT_ERR_INVALID_ARG, "plane %lld has no owner", gp);
-                        long long run = to->z0 + to->n - gp;
-                        if (run > count - done) run = count - done;
-                        const char* src = buf + (size_t)done * pb;
-                        char* dst = dst_of(*to) + (size_t)(gp - to->z0) * pb;
-                        if (to->device != from.device || mp->overlap == 2) {   // (2: test hook -- the staged path between slabs of one device)
-                            if (to->recv_used + run > 2 * H) return mfail(NDWT_ERR_UNSUPPORTED, "internal: receive buffer of the overlapped synthesis exhausted");
-                            char* rb = to->recv + (size_t)to->recv_used * pb;
-                            to->recv_used += run;
-                            MHIP(hipSetDevice(to->device));
-                            MHIP(hipStreamWaitEvent(to->cstream, from.margins, 0));
-                            MRET(copy_run(mp, *to, rb, from, src, run, to->cstream));
-                            src = rb;
-                        } else if (to != &from) {
-                            MHIP(hipSetDevice(to->device));
-                            MHIP(hipStreamWaitEvent(to->stream, from.margins, 0));   // same memory: added straight from the producer's buffer
+            MRET(phase(mp, [&](size_t ti) -> int {
+                Slab& t = mp->slabs[ti];
+                MHIP(hipSetDevice(t.device));
+                struct Pending { char* dst; const char* src; long long run; };
+                std::vector<Pending> adds;
+                t.recv_used = 0;
+                for (auto& from : mp->slabs) {
+                    for (int side = 0; side < 2; ++side) {
+                        const long long count = side == 0 ? sa : sb;
+                        const long long g = side == 0 ? from.z0 - sa : from.z0 + from.n;
+                        const char* buf = side == 0 ? from.mb : from.mb + (size_t)(m + (m - sb)) * pb;
+                        long long done = 0;
+                        while (done < count) {
+                            const long long gp = ((g + done) % N + N) % N;
+                            Slab* to = owner_of(mp, gp);
+                            if (!to) return mfail(NDWT_ERR_INVALID_ARG, "plane %lld has no owner", gp);
+                            long long run = to->z0 + to->n - gp;
+                            if (run > count - done) run = count - done;
+                            if (to == &t) {
+                                const char* src = buf + (size_t)done * pb;
+                                char* dst = dst_of(t) + (size_t)(gp - t.z0) * pb;
+                                if (t.device != from.device || mp->overlap == 2) {   // (2: test hook -- the staged path between slabs of one device)
+                                    if (t.recv_used + run > 2 * H) return mfail(NDWT_ERR_UNSUPPORTED, "internal: receive buffer of the overlapped synthesis exhausted");
+                                    char* rb = t.recv + (size_t)t.recv_used * pb;
+                                    t.recv_used += run;
+                                    MHIP(hipStreamWaitEvent(t.cstream, from.margins, 0));
+                                    MRET(copy_run(mp, t, rb, from, src, run, t.cstream));
+                                    src = rb;
+                                } else if (&t != &from) {
+                                    MHIP(hipStreamWaitEvent(t.stream, from.margins, 0));   // same memory: added straight from the producer's buffer
+                                }
+                                adds.push_back({dst, src, run});
+                            }
+                            done += run;
                         }
-                        adds.push_back({to, dst, src, run});
-                        done += run;
                     }
                 }
-            }
-            for (auto& s : mp->slabs) {
-                MHIP(hipSetDevice(s.device));
-                MHIP(hipEventRecord(s.copied, s.cstream));
-                MHIP(hipStreamWaitEvent(s.stream, s.copied, 0));
-            }
-            for (auto& a : adds) MRET(add_planes(mp, *a.to, a.dst, a.src, a.run));
+                MHIP(hipEventRecord(t.copied, t.cstream));
+                MHIP(hipStreamWaitEvent(t.stream, t.copied, 0));
+                for (auto& a : adds) MRET(add_planes(mp, t, a.dst, a.src, a.run));
+                return barrier_record(mp, ti, wr);
+            }));
+            MRET(phase(mp, [&](size_t i) { return barrier_wait(mp, i, wr); }));
+            continue;
         } else if (scatter) {
             // zero-extended synthesis: plane k of the extended result = global plane z0 - sa + k.  The slab's own n planes go where
             // the result lives; the sa planes before and the sb planes after it are partial sums owed to their owners.
@@ -445,6 +568,8 @@ int ndwt_mplan_create(ndwt_mplan** out, int ndim, const int64_t* dims, const cha
     mp->dilation = dilation;
     mp->exchange = NDWT_EXCHANGE_SCATTER;
     mp->overlap = 1;
+    mp->threads = 1;
+    mp->team = nullptr;
     for (int a = 0; a < ndim; ++a) mp->dims[a] = dims[a];
     size_t pb = (dtype == NDWT_F32 ? 4 : 8) * (complexity == NDWT_COMPLEX_INTERLEAVED ? 2 : 1);
     for (int a = 0; a + 1 < ndim; ++a) pb *= (size_t)dims[a];
@@ -520,6 +645,7 @@ int ndwt_mplan_create(ndwt_mplan** out, int ndim, const int64_t* dims, const cha
 
 int ndwt_mplan_destroy(ndwt_mplan* mp) {
     if (!mp) return NDWT_OK;
+    team_destroy(mp);
     for (auto& s : mp->slabs) {
         (void)hipSetDevice(s.device);
         if (s.stream) (void)hipStreamSynchronize(s.stream);
@@ -561,6 +687,13 @@ int ndwt_mplan_set_overlap(ndwt_mplan* mp, int overlap) {
     return NDWT_OK;
 }
 
+int ndwt_mplan_set_threads(ndwt_mplan* mp, int threads) {
+    if (!mp) return mfail(NDWT_ERR_INVALID_ARG, "null plan");
+    mp->threads = threads ? 1 : 0;
+    if (!mp->threads) team_destroy(mp);
+    return NDWT_OK;
+}
+
 double ndwt_mplan_last_enqueue_us(const ndwt_mplan* mp) { return mp ? mp->last_enqueue_us : -1.0; }
 
 int ndwt_mplan_describe(const ndwt_mplan* mp, char* buf, int buflen) {
@@ -583,7 +716,9 @@ int ndwt_mdec(ndwt_mplan* mp, const void* const* x_slabs, void* const* y_slabs, 
     for (size_t i = 0; i < mp->slabs.size(); ++i)
         if (!x_slabs[i] || !y_slabs[i]) return mfail(NDWT_ERR_INVALID_ARG, "null slab pointer %zu", i);
     const auto t0 = std::chrono::steady_clock::now();
+    team_begin(mp);
     rc = mdec_core(mp, x_slabs, y_slabs, level);
+    team_end(mp);
     mp->last_enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     const int rs = sync_all(mp);                          // (also after an error: nothing stays queued on buffers the caller owns)
     return rc ? rc : rs;
@@ -596,7 +731,9 @@ int ndwt_mrec(ndwt_mplan* mp, const void* const* y_slabs, void* const* x_slabs, 
     for (size_t i = 0; i < mp->slabs.size(); ++i)
         if (!x_slabs[i] || !y_slabs[i]) return mfail(NDWT_ERR_INVALID_ARG, "null slab pointer %zu", i);
     const auto t0 = std::chrono::steady_clock::now();
+    team_begin(mp);
     rc = mrec_core(mp, y_slabs, x_slabs, level);
+    team_end(mp);
     mp->last_enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     const int rs = sync_all(mp);
     return rc ? rc : rs;
@@ -629,7 +766,9 @@ int ndwt_mdec_host(ndwt_mplan* mp, const void* x_host, void* y_host, int level) 
         MHIP(hipMemcpyAsync(s.xbuf, (const char*)x_host + (size_t)s.z0 * pb, (size_t)s.n * pb, hipMemcpyHostToDevice, s.stream));
     }
     MRET(level_barrier(mp, 1));                           // every slab of x is in place before a neighbour reads its halo planes
+    team_begin(mp);
     rc = mdec_core(mp, xs.data(), ys.data(), level);
+    team_end(mp);
     if (rc == NDWT_OK)
         for (auto& s : mp->slabs) {
             MHIP(hipSetDevice(s.device));
@@ -655,7 +794,9 @@ int ndwt_mrec_host(ndwt_mplan* mp, const void* y_host, void* x_host, int level) 
             MHIP(hipMemcpyAsync(s.coef + (size_t)(b * s.n) * pb, (const char*)y_host + (size_t)(b * N + s.z0) * pb, (size_t)s.n * pb, hipMemcpyHostToDevice, s.stream));
     }
     MRET(level_barrier(mp, 1));
+    team_begin(mp);
     rc = mrec_core(mp, ys.data(), xs.data(), level);
+    team_end(mp);
     if (rc == NDWT_OK)
         for (auto& s : mp->slabs) {
             MHIP(hipSetDevice(s.device));

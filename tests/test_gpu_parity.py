@@ -1106,6 +1106,11 @@ def test_single_process_multi_device_plan(dims, wn, level, precision, cplx, dila
         assert np.array_equal(yo, ref["y"]) and np.array_equal(ro, ref["r"]), ov
         assert np.array_equal(yo, yk)
     mp.set_overlap(1)
+    # one host thread per slab queues that slab's work (default) / the calling thread queues everything: the same work on the same streams
+    for th in (False, True, False, True):
+        mp.set_threads(th)
+        for _ in range(2):
+            assert np.array_equal(mp.dec(xk, level), ref["y"]) and np.array_equal(mp.rec(c), ref["r"]), th
     # device-resident form: one tensor per slab, read and written in place
     dev = torch.device("cuda", 0)
     xs = [torch.from_numpy(xk[z0:z0 + n]).to(dev) for _, z0, n in sl]

@@ -14,8 +14,8 @@ G = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 wname = sys.argv[2] if len(sys.argv) > 2 else "db4"
 level = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 n = 512
-for overlap in (True, False):
-    mp = api.MultiPlan([n, n, n], [wname] * 3, torch.float32, [0] * G, pres_l2_norm=True, max_level=level).set_overlap(overlap)
+for overlap, threads in ((True, True), (True, False), (False, True), (False, False)):
+    mp = api.MultiPlan([n, n, n], [wname] * 3, torch.float32, [0] * G, pres_l2_norm=True, max_level=level).set_overlap(overlap).set_threads(threads)
     xs = [torch.randn(nz, n, n, device="cuda") for (_, _, nz) in mp.slabs()]
     ys = mp.dec_device(xs, level)
     rs = mp.rec_device(ys)
@@ -28,6 +28,6 @@ for overlap in (True, False):
         qr += L.lib().ndwt_mplan_last_enqueue_us(mp._h)
         wall += time.perf_counter() - t0
     err = max(float((r - x).abs().max()) for r, x in zip(rs, xs))
-    print(f"{G} slabs on one GPU, {wname} {level} levels, overlap={overlap}: queueing dec {qd / reps:7.1f} us + rec {qr / reps:7.1f} us per call; "
+    print(f"{G} slabs on one GPU, {wname} {level} levels, overlap={overlap}, one host thread per slab={threads}: queueing dec {qd / reps:7.1f} us + rec {qr / reps:7.1f} us per call; "
           f"wall {wall / reps * 1e3:6.2f} ms per dec+rec (all slabs on ONE device: /{G} = {wall / reps * 1e3 / G:5.2f} ms per device); max |rec - x| {err:.1e}")
     del mp, xs, ys, rs
