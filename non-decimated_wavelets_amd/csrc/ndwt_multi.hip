@@ -761,20 +761,26 @@ int ndwt_mdec_host(ndwt_mplan* mp, const void* x_host, void* y_host, int level) 
     const long long nbt = (long long)ndwt_num_bands(mp->ndim, level);
     std::vector<void*> xs, ys;
     MRET(host_buffers(mp, xs, ys));
-    for (auto& s : mp->slabs) {
+    // the copies between the host arrays and the slabs are queued by the slabs' own threads too: from pageable memory (what MATLAB holds) a
+    // copy occupies its calling thread until it is staged, and one thread would serve the devices' links one after the other
+    team_begin(mp);
+    rc = phase(mp, [&](size_t i) -> int {
+        Slab& s = mp->slabs[i];
         MHIP(hipSetDevice(s.device));
         MHIP(hipMemcpyAsync(s.xbuf, (const char*)x_host + (size_t)s.z0 * pb, (size_t)s.n * pb, hipMemcpyHostToDevice, s.stream));
-    }
-    MRET(level_barrier(mp, 1));                           // every slab of x is in place before a neighbour reads its halo planes
-    team_begin(mp);
-    rc = mdec_core(mp, xs.data(), ys.data(), level);
-    team_end(mp);
+        return NDWT_OK;
+    });
+    if (rc == NDWT_OK) rc = level_barrier(mp, 1);         // every slab of x is in place before a neighbour reads its halo planes
+    if (rc == NDWT_OK) rc = mdec_core(mp, xs.data(), ys.data(), level);
     if (rc == NDWT_OK)
-        for (auto& s : mp->slabs) {
+        rc = phase(mp, [&](size_t i) -> int {
+            Slab& s = mp->slabs[i];
             MHIP(hipSetDevice(s.device));
             for (long long b = 0; b < nbt; ++b)
                 MHIP(hipMemcpyAsync((char*)y_host + (size_t)(b * N + s.z0) * pb, s.coef + (size_t)(b * s.n) * pb, (size_t)s.n * pb, hipMemcpyDeviceToHost, s.stream));
-        }
+            return NDWT_OK;
+        });
+    team_end(mp);
     const int rs = sync_all(mp);
     return rc ? rc : rs;
 }
@@ -788,20 +794,24 @@ int ndwt_mrec_host(ndwt_mplan* mp, const void* y_host, void* x_host, int level) 
     const long long nbt = (long long)ndwt_num_bands(mp->ndim, level);
     std::vector<void*> xs, ys;
     MRET(host_buffers(mp, xs, ys));
-    for (auto& s : mp->slabs) {
+    team_begin(mp);
+    rc = phase(mp, [&](size_t i) -> int {
+        Slab& s = mp->slabs[i];
         MHIP(hipSetDevice(s.device));
         for (long long b = 0; b < nbt; ++b)
             MHIP(hipMemcpyAsync(s.coef + (size_t)(b * s.n) * pb, (const char*)y_host + (size_t)(b * N + s.z0) * pb, (size_t)s.n * pb, hipMemcpyHostToDevice, s.stream));
-    }
-    MRET(level_barrier(mp, 1));
-    team_begin(mp);
-    rc = mrec_core(mp, ys.data(), xs.data(), level);
-    team_end(mp);
+        return NDWT_OK;
+    });
+    if (rc == NDWT_OK) rc = level_barrier(mp, 1);
+    if (rc == NDWT_OK) rc = mrec_core(mp, ys.data(), xs.data(), level);
     if (rc == NDWT_OK)
-        for (auto& s : mp->slabs) {
+        rc = phase(mp, [&](size_t i) -> int {
+            Slab& s = mp->slabs[i];
             MHIP(hipSetDevice(s.device));
             MHIP(hipMemcpyAsync((char*)x_host + (size_t)s.z0 * pb, s.xbuf, (size_t)s.n * pb, hipMemcpyDeviceToHost, s.stream));
-        }
+            return NDWT_OK;
+        });
+    team_end(mp);
     const int rs = sync_all(mp);
     return rc ? rc : rs;
 }
