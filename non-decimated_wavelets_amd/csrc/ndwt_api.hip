@@ -523,7 +523,9 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
     int rc = -1;
     if constexpr (sizeof(T) == 4) {
         if (use_y) {
-            rc = ew == 4 ? (vec4 ? launch_inv3y4_f32(a, Lp, variant == 5 ? 1 : 2, td, s) : -1)
+            // (tap stride 4, 8 taps: the x stage in scatter form -- 512^3 db4 1.78 -> 1.52 ms per level; 6 taps 1.117 / 1.110: the gather form
+            //  stays; variant_inv 10 = scatter form for 4 / 6 taps too, 11 = gather form)
+            rc = ew == 4 ? (vec4 ? launch_inv3y4_f32(a, Lp, variant == 5 ? 1 : 2, td, s, p->variant_inv == 10 || (Lp == 8 && p->variant_inv != 11)) : -1)
                  : ew == 2 ? launch_inv3yc_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s)
                  // real data on rows of whole groups of 4, 10 .. 20 taps: the x stage in scatter form (512^3 per launch db5 1.18 -> 1.09 ms,
                  // db6 1.34 -> 1.23, db9 2.66 -> 2.41, db10 3.08 -> 2.87; 8 taps: 1.04 either way, the gather form stays.  A/B: variant_inv

@@ -429,6 +429,17 @@ struct PkF32 {
         acc += x * (NEG ? -tp[HI] : tp[HI]);
 #endif
     }
+    // acc = x * (t, t), t = tp[HI], negated if NEG: the first term of a sum
+    template <int HI, bool NEG> static NDWT_DEV void mul_s(v2& acc, const v2 x, const v2 tp) {
+#ifndef NDWT_HOST_EMU
+        if constexpr (HI == 0 && !NEG) asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(acc) : "v"(x), "s"(tp));
+        else if constexpr (HI == 1 && !NEG) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(acc) : "v"(x), "s"(tp));
+        else if constexpr (HI == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(acc) : "v"(x), "s"(tp));
+        else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(acc) : "v"(x), "s"(tp));
+#else
+        acc = x * (NEG ? -tp[HI] : tp[HI]);
+#endif
+    }
     // acc += x * ANALYSIS low-pass tap J (HIGH = false) or high-pass tap J = (-1)^J low-pass tap L-1-J, from the pairs lo[m] = (t[2m], t[2m+1])
     template <int L, int J, bool HIGH> static NDWT_DEV void tap_ana(v2& acc, const v2 x, const v2 (&lo)[L / 2]) {
         constexpr int jj = HIGH ? L - 1 - J : J;
@@ -1415,7 +1426,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
     static constexpr int XH = XH_;
     static constexpr bool UNIYZ = UNIYZ_;
     static constexpr bool XSC = XSC_;
-    static_assert(!XSC || (EW_ == 1 && XH_ == 0), "scatter x stage: real data, rows without extra lanes");
+    static_assert(!XSC || ((EW_ == 1 || EW_ == 4) && XH_ == 0), "scatter x stage: real data (tap stride 1 or 4), rows without extra lanes");
     // scatter x stage: own sample c (0..3) reaches the output pair P = (2P, 2P+1), counted from the lane's first x, through the tap pair
     // K = c + LH - 2P (0 <= K <= L); pair P belongs to the lane floor(P / 2) away, as its pair P mod 2
     static constexpr int PMIN = -(LH / 2), PMAX = (3 + LH) / 2, NPQ = PMAX - PMIN + 1;
@@ -1452,7 +1463,8 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
         v4 raw[DEPTH][NRND][8];    // 4 x of every band of this lane's row(s); DEPTH 2: the set index is the plane's parity
         unsigned off[NRND][NE];    // BYTE offsets inside a plane (kNoRow: this lane holds no row and loads nothing)
         v2 P[NYI][2];              // y-synthesised (x0, x1) pairs of the newest plane: z-low / z-high inputs of the z stage
-        v2 xq[XSC ? NPQ : 1];      // scatter x stage: partial sums of the output pairs PMIN .. PMAX of one stream (short-lived)
+        v2 xq[XSC ? (EW_ == 4 ? 8 : NPQ) : 1];   // scatter x stage: partial sums of the output pairs PMIN .. PMAX of one stream (short-lived);
+                                   // tap stride 4: the sums on their way to the right / left, [generation][direction][pair of the lane]
         v2 xo[XSC ? 2 : 1][2];     // scatter x stage: the lane's two output pairs of the z-low / z-high stream of a y-bit
         unsigned ooff[NYI];        // byte offset of this thread's output pair inside a plane
         int ostore[NYI];           // outputs this thread stores: 0 none (outside the volume), 1 the first x only, 2 the pair
@@ -1786,10 +1798,96 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
             NDWT_SEND
         NDWT_SEND
     }
+    // acc = / += w * (synthesis tap J, low- or high-pass) from the pairs xl[m] = (lo[2m], lo[2m+1]); FIRST: the first term of a sum
+    template <int J, bool HIGH, bool FIRST> static NDWT_DEV void tap_first(v2& acc, const v2 w, const v2 (&lo)[L / 2]) {
+        if constexpr (!FIRST) tap_fma<J, HIGH>(acc, w, lo);
+        else {
+            constexpr int jj = HIGH ? L - 1 - J : J;
+            PkF32::mul_s<jj & 1, HIGH && (J % 2 == 0)>(acc, w, lo[jj / 2]);
+        }
+    }
+    // Scatter form of the x stage at tap stride 4 (EW = 4: a lane's 4 scalars are one x of 4 sub-lattices, the lane D away holds the
+    // element D steps away on each).  The gather form shifts every band's 4 scalars past L - 1 lanes (28 v_mov_b32_dpp per band with 8
+    // taps: 224 per lane and plane against 128 packed FMAs).  Here a lane multiplies its own scalars by every tap and the SUMS walk: the
+    // sum on its way to the right takes, at every lane it passes, that lane's term for the same destination (S_k = own * t[LH - k] +
+    // S_{k+1} of the lane to the left), likewise to the left -- one v_add_f32_dpp per scalar and hop, once per output stream instead
+    // of once per band: 112 instead of 224, no zeroed accumulators.
+    template <int SET, class Exec>
+    static NDWT_DEV void xsyn_scatter4(Exec& ex, Shared& sh, const RegTaps& tp, int buf) {
+        NDWT_SFOR(k, NRND)
+            NDWT_SFOR(yb, 2)
+                NDWT_SFOR(zb, 2)
+                    // generation g of the walking sums lives in xq[4 (g & 1) + 2 dir + q]: a pass reads its neighbour's previous generation
+                    NDWT_SFOR(g, (LH > RH ? LH : RH))
+                        ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+                            (void)tid;
+                            const v4 rl = st.raw[SET][k][0 + 2 * yb + 4 * zb], rh = st.raw[SET][k][1 + 2 * yb + 4 * zb];
+                            NDWT_SFOR(q, 2)
+                                const v2 wl = {rl[2 * q], rl[2 * q + 1]}, wh = {rh[2 * q], rh[2 * q + 1]};
+                                if constexpr (g < LH) {                       // to the right: destination LH - g lanes away, tap g
+                                    v2 a;
+                                    tap_first<g, false, true>(a, wl, tp.xl);
+                                    tap_first<g, true, false>(a, wh, tp.xl);
+                                    if constexpr (g > 0) {
+                                        a.x += NDWT_LANE_SHIFT(ex, tid, -1, s.xq[4 * ((g - 1) & 1) + q].x);
+                                        a.y += NDWT_LANE_SHIFT(ex, tid, -1, s.xq[4 * ((g - 1) & 1) + q].y);
+                                    }
+                                    st.xq[4 * (g & 1) + q] = a;
+                                }
+                                if constexpr (g < RH) {                       // to the left: destination RH - g lanes away, tap L - 1 - g
+                                    v2 a;
+                                    tap_first<L - 1 - g, false, true>(a, wl, tp.xl);
+                                    tap_first<L - 1 - g, true, false>(a, wh, tp.xl);
+                                    if constexpr (g > 0) {
+                                        a.x += NDWT_LANE_SHIFT(ex, tid, 1, s.xq[4 * ((g - 1) & 1) + 2 + q].x);
+                                        a.y += NDWT_LANE_SHIFT(ex, tid, 1, s.xq[4 * ((g - 1) & 1) + 2 + q].y);
+                                    }
+                                    st.xq[4 * (g & 1) + 2 + q] = a;
+                                }
+                            NDWT_SEND
+                        });
+                    NDWT_SEND
+                    // the lane's own term (tap LH) + what has arrived from the left (generation LH - 1) and from the right (generation RH - 1)
+                    ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+                        (void)tid;
+                        const v4 rl = st.raw[SET][k][0 + 2 * yb + 4 * zb], rh = st.raw[SET][k][1 + 2 * yb + 4 * zb];
+                        NDWT_SFOR(q, 2)
+                            const v2 wl = {rl[2 * q], rl[2 * q + 1]}, wh = {rh[2 * q], rh[2 * q + 1]};
+                            v2 o;
+                            tap_first<LH, false, true>(o, wl, tp.xl);
+                            tap_first<LH, true, false>(o, wh, tp.xl);
+                            if constexpr (LH > 0) {
+                                o.x += NDWT_LANE_SHIFT(ex, tid, -1, s.xq[4 * ((LH - 1) & 1) + q].x);
+                                o.y += NDWT_LANE_SHIFT(ex, tid, -1, s.xq[4 * ((LH - 1) & 1) + q].y);
+                            }
+                            if constexpr (RH > 0) {
+                                o.x += NDWT_LANE_SHIFT(ex, tid, 1, s.xq[4 * ((RH - 1) & 1) + 2 + q].x);
+                                o.y += NDWT_LANE_SHIFT(ex, tid, 1, s.xq[4 * ((RH - 1) & 1) + 2 + q].y);
+                            }
+                            st.xo[zb][q] = pinned_v(o);
+                        NDWT_SEND
+                    });
+                NDWT_SEND
+                ex.each([&](int tid, State& st) __attribute__((always_inline)) {
+                    int ug, r;
+                    bool valid;
+                    lane_item(tid, k, ug, r, valid);
+                    if (valid && ug >= GL + XH && ug < GL + XH + TX / 4) {
+                        const chunk c0 = {st.xo[0][0].x, st.xo[0][0].y, st.xo[1][0].x, st.xo[1][0].y};
+                        const chunk c1 = {st.xo[0][1].x, st.xo[0][1].y, st.xo[1][1].x, st.xo[1][1].y};
+                        chunk* row = sh.xs[buf][yb][r];
+                        row[LD::S(2 * (ug - GL - XH))] = c0;
+                        row[LD::S(2 * (ug - GL - XH) + 1)] = c1;
+                    }
+                });
+            NDWT_SEND
+        NDWT_SEND
+    }
     // the x stage of register set SET into xs[buf], in the form this instance uses
     template <int SET, class Exec>
     static NDWT_DEV void xstage(Exec& ex, Shared& sh, const RegTaps& tp, int buf) {
-        if constexpr (XSC) xsyn_scatter<SET>(ex, sh, tp, buf);
+        if constexpr (XSC && EW == 4) xsyn_scatter4<SET>(ex, sh, tp, buf);
+        else if constexpr (XSC) xsyn_scatter<SET>(ex, sh, tp, buf);
         else ex.each([&](int tid, State& st) __attribute__((always_inline)) { xsyn<SET>(ex, st, sh, tp, buf, tid); });
     }
 

@@ -30,7 +30,7 @@ int launch_inv3y_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, c
 // the same kernel with its x stage in scatter form (rows of whole groups of 4, two register sets); -1: no instance for this tap length
 int launch_inv3ys_f32(const Fused3Args<float>& a, int Lp, int depth, const void* taps_dev, hipStream_t s, int uniform_yz);
 int launch_inv3yc_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, const void* taps_dev, hipStream_t s);   // interleaved complex
-int launch_inv3y4_f32(const Fused3Args<float>& a, int Lp, int depth, const void* taps_dev, hipStream_t s);   // a level dilated by 4 (EW = 4), vec4 rows
+int launch_inv3y4_f32(const Fused3Args<float>& a, int Lp, int depth, const void* taps_dev, hipStream_t s, int scatter = 0);   // a level dilated by 4 (EW = 4), vec4 rows
 
 // level 1 of a denoising step in one launch (Den3: in[0] = x, in[1] = approximation band) and the approximation-only analysis
 // that goes with it (tall 64 x 32 tile); float, real data, tap lengths 2 .. 8: ndwt_fused3_f32_den.hip

@@ -38,7 +38,22 @@ template <int LL, int DEPTH> static int go4(const Fused3Args<float>& a, const vo
     unused.Lp = LL;
     return launch_fused3<K>(a, unused, taps_dev, s);
 }
-int launch_inv3y4_f32(const Fused3Args<float>& a, int Lp, int depth, const void* taps_dev, hipStream_t s) {
+// the same with the x stage in scatter form (the sums walk from lane to lane instead of the samples: Inv3Y::xsyn_scatter4)
+template <int LL, int DEPTH> static int go4s(const Fused3Args<float>& a, const void* taps_dev, hipStream_t s) {
+    typedef Inv3Y<float, LL, inv3y_tx(LL, 4), inv3y_ty(LL, 4), 1024, true, 4, DEPTH, 4, 0, 0, false, true> K;
+    FusedTapsD unused;
+    unused.Lp = LL;
+    return launch_fused3<K>(a, unused, taps_dev, s);
+}
+int launch_inv3y4_f32(const Fused3Args<float>& a, int Lp, int depth, const void* taps_dev, hipStream_t s, int scatter) {
+    if (scatter) {
+        switch (Lp) {
+            case 4: return go4s<4, 1>(a, taps_dev, s);
+            case 6: return go4s<6, 1>(a, taps_dev, s);
+            case 8: return depth == 2 ? go4s<8, 2>(a, taps_dev, s) : go4s<8, 1>(a, taps_dev, s);
+            default: break;
+        }
+    }
     switch (Lp) {
         case 2: return depth == 2 ? go4<2, 2>(a, taps_dev, s) : go4<2, 1>(a, taps_dev, s);
         case 4: return go4<4, 1>(a, taps_dev, s);

@@ -21,6 +21,7 @@ int emu_y_prod(int depth, int Lp, int vec4, ndwt::Fused3Args<float>& a, const do
 int emu_yc_small(int depth, int Lp, int vec4, ndwt::Fused3Args<float>& a, const double* lo, const double* hi);
 int emu_y_dilated(int ew, int depth, int Lp, ndwt::Fused3Args<float>& a, const double* lo, const double* hi);
 int emu_y_scatter(int small, int Lp, ndwt::Fused3Args<float>& a, const double* lo, const double* hi);
+int emu_y_dilated4s(int Lp, ndwt::Fused3Args<float>& a, const double* lo, const double* hi);
 
 namespace {
 
@@ -174,6 +175,10 @@ int emu3(int Lp, int vec4, const T* in, T* out, int n1, int n2, int n3, int nbat
             typedef ndwt::Fused3Tile<T, false, 1> DF;
             typedef ndwt::Fused3Tile<T, true, 4> DI;
             if constexpr (INV) {
+                if (variant == 10 && vec4 && Lp >= 4 && Lp <= 8) {         // ... with the x stage in scatter form (the sums walk from lane to lane)
+                    geometry(ndwt::inv3y_tx(Lp, 4), ndwt::inv3y_ty(Lp, 4));
+                    return emu_y_dilated4s(Lp, a, lo, hi);
+                }
                 if ((variant == 5 || variant == 8) && vec4 && Lp <= 8) {   // the pair-packed kernel on whole-lane x shifts (EW = 4), production tiles
                     geometry(ndwt::inv3y_tx(Lp, 4), ndwt::inv3y_ty(Lp, 4));
                     return emu_y_dilated(4, variant == 5 ? 1 : 2, Lp, a, lo, hi);
@@ -468,6 +473,20 @@ int emu_y_scatter(int small, int Lp, ndwt::Fused3Args<float>& a, const double* l
         case 12: return uni ? run_ys<12, ndwt::inv3y_tx(12), ndwt::inv3y_ty(12), 1024, 2, ndwt::inv3y_zlds(12, 2), true>(a, lo, hi)
                             : run_ys<12, ndwt::inv3y_tx(12), ndwt::inv3y_ty(12), 1024, 2, ndwt::inv3y_zlds(12, 2), false>(a, lo, hi);
         case 20: return run_ys<20, ndwt::inv3y_tx(20), ndwt::inv3y_ty(20), 1024, 1, ndwt::inv3y_zlds(20, 1), true>(a, lo, hi);
+        default: return -1;
+    }
+}
+#endif
+#if EMU_IN(17)
+// a level dilated by 4 through Inv3Y<.., EW = 4, XSC>: the library's instances (8 taps: two register sets)
+template <int LL, int D> static int run_y4s(ndwt::Fused3Args<float>& a, const double* lo, const double* hi) {
+    return runY<ndwt::Inv3Y<float, LL, ndwt::inv3y_tx(LL, 4), ndwt::inv3y_ty(LL, 4), 1024, true, 2, D, 4, 0, 0, false, true>, float>(a, lo, hi);
+}
+int emu_y_dilated4s(int Lp, ndwt::Fused3Args<float>& a, const double* lo, const double* hi) {
+    switch (Lp) {
+        case 4: return run_y4s<4, 1>(a, lo, hi);
+        case 6: return run_y4s<6, 1>(a, lo, hi);
+        case 8: return run_y4s<8, 2>(a, lo, hi);
         default: return -1;
     }
 }
