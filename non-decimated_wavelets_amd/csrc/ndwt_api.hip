@@ -526,7 +526,9 @@ static int fused3_run(const ndwt_plan* p, bool inverse, int Lp, const T* const* 
             // (tap stride 4, 8 taps: the x stage in scatter form -- 512^3 db4 1.78 -> 1.52 ms per level; 6 taps 1.117 / 1.110: the gather form
             //  stays; variant_inv 10 = scatter form for 4 / 6 taps too, 11 = gather form)
             rc = ew == 4 ? (vec4 ? launch_inv3y4_f32(a, Lp, variant == 5 ? 1 : 2, td, s, p->variant_inv == 10 || (Lp == 8 && p->variant_inv != 11)) : -1)
-                 : ew == 2 ? launch_inv3yc_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s)
+                 // (interleaved pairs: the scatter form from 10 taps on -- complex64 384^3 rec of 3 levels db5 3.78 -> 3.66 ms, db6 5.00 -> 4.66, db8 6.71 -> 5.83;
+                 //  8 taps: 3.07 either way, and real data at tap stride 2 4 % SLOWER (0.97 -> 1.02 ms per level): the gather form stays there)
+                 : ew == 2 ? launch_inv3yc_f32(a, Lp, vec4, variant == 5 ? 1 : 2, td, s, p->variant_inv == 10 || (Lp >= 10 && p->variant_inv != 11))
                  // real data on rows of whole groups of 4, 10 .. 20 taps: the x stage in scatter form (512^3 per launch db5 1.18 -> 1.09 ms,
                  // db6 1.34 -> 1.23, db9 2.66 -> 2.41, db10 3.08 -> 2.87; 8 taps: 1.04 either way, the gather form stays.  A/B: variant_inv
                  // 10 = scatter form for 8 taps too, 11 = gather form for every tap length)

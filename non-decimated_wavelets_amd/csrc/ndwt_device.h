@@ -1426,13 +1426,17 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
     static constexpr int XH = XH_;
     static constexpr bool UNIYZ = UNIYZ_;
     static constexpr bool XSC = XSC_;
-    static_assert(!XSC || ((EW_ == 1 || EW_ == 4) && XH_ == 0), "scatter x stage: real data (tap stride 1 or 4), rows without extra lanes");
+    static_assert(!XSC || XH_ == 0, "scatter x stage: rows without extra lanes");
     // scatter x stage: own sample c (0..3) reaches the output pair P = (2P, 2P+1), counted from the lane's first x, through the tap pair
     // K = c + LH - 2P (0 <= K <= L); pair P belongs to the lane floor(P / 2) away, as its pair P mod 2
     static constexpr int PMIN = -(LH / 2), PMAX = (3 + LH) / 2, NPQ = PMAX - PMIN + 1;
     static constexpr int fdiv2(int p) { return p >= 0 ? p / 2 : -((-p + 1) / 2); }
     static constexpr int DFAR = fdiv2(PMAX) > -fdiv2(PMIN) ? fdiv2(PMAX) : -fdiv2(PMIN);   // farthest lane a partial sum travels
-    static_assert(!XSC || (fdiv2(PMAX) <= GL && -fdiv2(PMIN) <= GR), "halo lanes cover the reach of the partial sums");
+    // EW = 2 (interleaved complex data / a level dilated by 2): the lane's two ELEMENTS c = 0, 1 (a (re, im) pair each) reach the output
+    // elements n = c + LH - j, j = 0 .. L-1, i.e. -RH .. LH + 1; element n belongs to the lane floor(n / 2) away, as its element n mod 2
+    static constexpr int SMIN = EW_ == 2 ? -RH : PMIN, SMAX = EW_ == 2 ? LH + 1 : PMAX, NSQ = SMAX - SMIN + 1;
+    static constexpr int SFAR = fdiv2(SMAX) > -fdiv2(SMIN) ? fdiv2(SMAX) : -fdiv2(SMIN);
+    static_assert(!XSC || EW_ == 4 || (fdiv2(SMAX) <= GL && -fdiv2(SMIN) <= GR), "halo lanes cover the reach of the partial sums");
     static constexpr int NG = TX / 4 + GL + GR + 2 * XH; // lanes per haloed row
     static constexpr int NR = TY + L - 1;                // haloed rows: loaded, x-synthesised, kept in LDS
     static constexpr int RPW = 64 / NG;                  // rows per wave
@@ -1463,7 +1467,7 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
         v4 raw[DEPTH][NRND][8];    // 4 x of every band of this lane's row(s); DEPTH 2: the set index is the plane's parity
         unsigned off[NRND][NE];    // BYTE offsets inside a plane (kNoRow: this lane holds no row and loads nothing)
         v2 P[NYI][2];              // y-synthesised (x0, x1) pairs of the newest plane: z-low / z-high inputs of the z stage
-        v2 xq[XSC ? (EW_ == 4 ? 8 : NPQ) : 1];   // scatter x stage: partial sums of the output pairs PMIN .. PMAX of one stream (short-lived);
+        v2 xq[XSC ? (EW_ == 4 ? 8 : NSQ) : 1];   // scatter x stage: partial sums of the output pairs PMIN .. PMAX of one stream (short-lived);
                                    // tap stride 4: the sums on their way to the right / left, [generation][direction][pair of the lane]
         v2 xo[XSC ? 2 : 1][2];     // scatter x stage: the lane's two output pairs of the z-low / z-high stream of a y-bit
         unsigned ooff[NYI];        // byte offset of this thread's output pair inside a plane
@@ -1718,46 +1722,66 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
         else if constexpr (!HIGH) PkF32::mul_bt<H, false, false, false>(acc, w, tp.xp[K]);
         else PkF32::mul_bt<H, true, K % 2 == 0, K % 2 != 0>(acc, w, tp.xp[L - K]);
     }
-    static constexpr bool xsc_has(int P) { return P >= PMIN && P <= PMAX; }
-    // x stage in scatter form (XSC).  Runs at workgroup level: the partial sums of the neighbouring lanes are read between its passes
-    // (one straight line of code on the GPU; the host emulation finishes a pass for every lane before the next one reads them).
+    static constexpr bool xsc_has(int P) { return P >= SMIN && P <= SMAX; }
+    // acc = / += w * (synthesis tap J, low- or high-pass) from the pairs xl[m] = (lo[2m], lo[2m+1]); FIRST: the first term of a sum
+    template <int J, bool HIGH, bool FIRST> static NDWT_DEV void tap_first(v2& acc, const v2 w, const v2 (&lo)[L / 2]) {
+        if constexpr (!FIRST) tap_fma<J, HIGH>(acc, w, lo);
+        else {
+            constexpr int jj = HIGH ? L - 1 - J : J;
+            PkF32::mul_s<jj & 1, HIGH && (J % 2 == 0)>(acc, w, lo[jj / 2]);
+        }
+    }
+    // x stage in scatter form (XSC; EW = 1 real data, EW = 2 interleaved complex data / a level dilated by 2).  Runs at workgroup level: the
+    // partial sums of the neighbouring lanes are read between its passes (one straight line of code on the GPU; the host emulation finishes a
+    // pass for every lane before the next one reads them).
     template <int SET, class Exec>
     static NDWT_DEV void xsyn_scatter(Exec& ex, Shared& sh, const RegTaps& tp, int buf) {
         NDWT_SFOR(k, NRND)
             NDWT_SFOR(yb, 2)
                 NDWT_SFOR(zb, 2)
-                    // pass 1: the lane's 4 samples of the x-low and the x-high band times every tap pair they reach
+                    // pass 1: the lane's 4 scalars of the x-low and the x-high band times every tap (pair) they reach
                     ex.each([&](int, State& st) __attribute__((always_inline)) {
-                        NDWT_SFOR(pi, NPQ)
-                            constexpr int P = PMIN + pi;
+                        NDWT_SFOR(pi, NSQ)
+                            constexpr int P = SMIN + pi;
                             NDWT_SFOR(xb, 2)
                                 const v4 r = st.raw[SET][k][xb + 2 * yb + 4 * zb];
                                 const v2 w01 = {r[0], r[1]}, w23 = {r[2], r[3]};
-                                NDWT_SFOR(c, 4)
-                                    constexpr int K = c + LH - 2 * P;
-                                    if constexpr (K >= 0 && K <= L) {
-                                        // the first valid (xb, c) of this pair starts the sum
-                                        constexpr int c_first = (2 * P - LH) > 0 ? (2 * P - LH) : 0;
-                                        constexpr bool first = xb == 0 && c == c_first;
-                                        xtap_first<c % 2, K, xb == 1, first>(st.xq[pi], c < 2 ? w01 : w23, tp);
-                                    }
-                                NDWT_SEND
+                                if constexpr (EW == 1) {
+                                    NDWT_SFOR(c, 4)
+                                        constexpr int K = c + LH - 2 * P;
+                                        if constexpr (K >= 0 && K <= L) {
+                                            // the first valid (xb, c) of this pair starts the sum
+                                            constexpr int c_first = (2 * P - LH) > 0 ? (2 * P - LH) : 0;
+                                            constexpr bool first = xb == 0 && c == c_first;
+                                            xtap_first<c % 2, K, xb == 1, first>(st.xq[pi], c < 2 ? w01 : w23, tp);
+                                        }
+                                    NDWT_SEND
+                                } else {
+                                    NDWT_SFOR(c, 2)                  // element c = (re, im) -> output element P through tap c - P + LH
+                                        constexpr int J = c - P + LH;
+                                        if constexpr (J >= 0 && J < L) {
+                                            constexpr int c_first = (P - LH) > 0 ? (P - LH) : 0;
+                                            constexpr bool first = xb == 0 && c == c_first;
+                                            tap_first<J, xb == 1, first>(st.xq[pi], c == 0 ? w01 : w23, tp.xl);
+                                        }
+                                    NDWT_SEND
+                                }
                             NDWT_SEND
                         NDWT_SEND
                     });
                     // passes 2 ..: sums that travel more than one lane are added to the next-nearer lane's sum for the same destination
-                    NDWT_SFOR(hh, (DFAR > 1 ? DFAR - 1 : 0))
-                        constexpr int h = DFAR - hh;     // DFAR .. 2
+                    NDWT_SFOR(hh, (SFAR > 1 ? SFAR - 1 : 0))
+                        constexpr int h = SFAR - hh;     // SFAR .. 2
                         ex.each([&](int tid, State& st) __attribute__((always_inline)) {
                             (void)tid;
                             NDWT_SFOR(q, 2)
                                 if constexpr (xsc_has(2 * h + q)) {          // to the right: lane i takes lane i-1's
-                                    constexpr int far = 2 * h + q - PMIN, near = 2 * (h - 1) + q - PMIN;
+                                    constexpr int far = 2 * h + q - SMIN, near = 2 * (h - 1) + q - SMIN;
                                     st.xq[near].x += NDWT_LANE_SHIFT(ex, tid, -1, s.xq[far].x);
                                     st.xq[near].y += NDWT_LANE_SHIFT(ex, tid, -1, s.xq[far].y);
                                 }
                                 if constexpr (xsc_has(-2 * h + q)) {         // to the left: lane i takes lane i+1's
-                                    constexpr int far = -2 * h + q - PMIN, near = -2 * (h - 1) + q - PMIN;
+                                    constexpr int far = -2 * h + q - SMIN, near = -2 * (h - 1) + q - SMIN;
                                     st.xq[near].x += NDWT_LANE_SHIFT(ex, tid, 1, s.xq[far].x);
                                     st.xq[near].y += NDWT_LANE_SHIFT(ex, tid, 1, s.xq[far].y);
                                 }
@@ -1768,14 +1792,14 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
                     ex.each([&](int tid, State& st) __attribute__((always_inline)) {
                         (void)tid;
                         NDWT_SFOR(q, 2)
-                            v2 o = st.xq[q - PMIN];
+                            v2 o = st.xq[q - SMIN];
                             if constexpr (xsc_has(2 + q)) {
-                                o.x += NDWT_LANE_SHIFT(ex, tid, -1, s.xq[2 + q - PMIN].x);
-                                o.y += NDWT_LANE_SHIFT(ex, tid, -1, s.xq[2 + q - PMIN].y);
+                                o.x += NDWT_LANE_SHIFT(ex, tid, -1, s.xq[2 + q - SMIN].x);
+                                o.y += NDWT_LANE_SHIFT(ex, tid, -1, s.xq[2 + q - SMIN].y);
                             }
                             if constexpr (xsc_has(-2 + q)) {
-                                o.x += NDWT_LANE_SHIFT(ex, tid, 1, s.xq[-2 + q - PMIN].x);
-                                o.y += NDWT_LANE_SHIFT(ex, tid, 1, s.xq[-2 + q - PMIN].y);
+                                o.x += NDWT_LANE_SHIFT(ex, tid, 1, s.xq[-2 + q - SMIN].x);
+                                o.y += NDWT_LANE_SHIFT(ex, tid, 1, s.xq[-2 + q - SMIN].y);
                             }
                             // (the sums are only stored under the lane's `valid` test below: without this the compiler sinks the two adds into
                             // that branch, away from their wave shifts, and the shifts stay v_mov_b32_dpp + v_add_f32 instead of v_add_f32_dpp)
@@ -1797,14 +1821,6 @@ template <typename T, int L_, int TX_, int TY_, int NT_, bool VEC4_, int WPE_ = 
                 });
             NDWT_SEND
         NDWT_SEND
-    }
-    // acc = / += w * (synthesis tap J, low- or high-pass) from the pairs xl[m] = (lo[2m], lo[2m+1]); FIRST: the first term of a sum
-    template <int J, bool HIGH, bool FIRST> static NDWT_DEV void tap_first(v2& acc, const v2 w, const v2 (&lo)[L / 2]) {
-        if constexpr (!FIRST) tap_fma<J, HIGH>(acc, w, lo);
-        else {
-            constexpr int jj = HIGH ? L - 1 - J : J;
-            PkF32::mul_s<jj & 1, HIGH && (J % 2 == 0)>(acc, w, lo[jj / 2]);
-        }
     }
     // Scatter form of the x stage at tap stride 4 (EW = 4: a lane's 4 scalars are one x of 4 sub-lattices, the lane D away holds the
     // element D steps away on each).  The gather form shifts every band's 4 scalars past L - 1 lanes (28 v_mov_b32_dpp per band with 8

@@ -29,7 +29,7 @@ int launch_inv3_f64(const Fused3Args<double>& a, const FusedTapsD& t, bool vec4,
 int launch_inv3y_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, const void* taps_dev, hipStream_t s, int uniform_yz = 0);
 // the same kernel with its x stage in scatter form (rows of whole groups of 4, two register sets); -1: no instance for this tap length
 int launch_inv3ys_f32(const Fused3Args<float>& a, int Lp, int depth, const void* taps_dev, hipStream_t s, int uniform_yz);
-int launch_inv3yc_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, const void* taps_dev, hipStream_t s);   // interleaved complex
+int launch_inv3yc_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, const void* taps_dev, hipStream_t s, int scatter = 0);   // interleaved complex
 int launch_inv3y4_f32(const Fused3Args<float>& a, int Lp, int depth, const void* taps_dev, hipStream_t s, int scatter = 0);   // a level dilated by 4 (EW = 4), vec4 rows
 
 // level 1 of a denoising step in one launch (Den3: in[0] = x, in[1] = approximation band) and the approximation-only analysis

@@ -17,7 +17,24 @@ template <int LL, bool V, int DEPTH> static int go(const Fused3Args<float>& a, c
         }                         \
         return vec4 ? go<LL, true, 1>(a, taps_dev, s) : go<LL, false, 1>(a, taps_dev, s);
 
-int launch_inv3yc_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, const void* taps_dev, hipStream_t s) {
+// the x stage in scatter form (Inv3Y::xsyn_scatter on (re, im) pairs): rows of whole groups of 4 scalars
+template <int LL, int DEPTH> static int gos(const Fused3Args<float>& a, const void* taps_dev, hipStream_t s) {
+    typedef Inv3Y<float, LL, inv3y_tx(LL, 2), inv3y_ty(LL, 2), 1024, true, 4, DEPTH, 2, 0, 0, false, true> K;
+    FusedTapsD unused;
+    unused.Lp = LL;
+    return launch_fused3<K>(a, unused, taps_dev, s);
+}
+int launch_inv3yc_f32(const Fused3Args<float>& a, int Lp, bool vec4, int depth, const void* taps_dev, hipStream_t s, int scatter) {
+    if (scatter && vec4) {
+        switch (Lp) {
+            case 8: return depth == 2 ? gos<8, 2>(a, taps_dev, s) : gos<8, 1>(a, taps_dev, s);
+            case 10: return gos<10, 1>(a, taps_dev, s);
+            case 12: return gos<12, 1>(a, taps_dev, s);
+            case 14: return gos<14, 1>(a, taps_dev, s);
+            case 16: return gos<16, 1>(a, taps_dev, s);
+            default: break;
+        }
+    }
     switch (Lp) {
         NDWT_INVYC_CASE(2, true)
         NDWT_INVYC_CASE(4, false)

@@ -22,6 +22,7 @@ int emu_yc_small(int depth, int Lp, int vec4, ndwt::Fused3Args<float>& a, const 
 int emu_y_dilated(int ew, int depth, int Lp, ndwt::Fused3Args<float>& a, const double* lo, const double* hi);
 int emu_y_scatter(int small, int Lp, ndwt::Fused3Args<float>& a, const double* lo, const double* hi);
 int emu_y_dilated4s(int Lp, ndwt::Fused3Args<float>& a, const double* lo, const double* hi);
+int emu_yc_scatter(int small, int Lp, ndwt::Fused3Args<float>& a, const double* lo, const double* hi);
 
 namespace {
 
@@ -193,6 +194,13 @@ int emu3(int Lp, int vec4, const T* in, T* out, int n1, int n2, int n3, int nbat
         return -1;
     }
     if (ew == 2) {      // interleaved complex: n1 counts scalars; lane-shift synthesis and LDS analysis kernels
+        if constexpr (INV && sizeof(T) == 4) {   // ... with the x stage in scatter form: small tile (every tap length), production tiles 10 .. 16 taps
+            if (variant == 10 && vec4 && Lp <= 16 && (small_tile || Lp >= 10)) {
+                if (small_tile) geometry(16, 8);
+                else geometry(ndwt::inv3y_tx(Lp, 2), ndwt::inv3y_ty(Lp, 2));
+                return emu_yc_scatter(small_tile ? 1 : 0, Lp, a, lo, hi);
+            }
+        }
         if constexpr (INV && sizeof(T) == 4) {   // pair-packed synthesis on (re, im) pairs: small tile, every tap length up to 16
             if ((variant == 5 || variant == 8) && small_tile && Lp <= 16) {
                 geometry(16, 8);
@@ -489,6 +497,28 @@ int emu_y_dilated4s(int Lp, ndwt::Fused3Args<float>& a, const double* lo, const 
         case 8: return run_y4s<8, 2>(a, lo, hi);
         default: return -1;
     }
+}
+#endif
+#if EMU_IN(18)
+// Inv3Y on (re, im) pairs with the x stage in scatter form (EW = 2, XSC)
+template <int LL, int TX, int TY, int NT, int D> static int run_ycs(ndwt::Fused3Args<float>& a, const double* lo, const double* hi) {
+    return runY<ndwt::Inv3Y<float, LL, TX, TY, NT, true, 2, D, 2, 0, 0, false, true>, float>(a, lo, hi);
+}
+int emu_yc_scatter(int small, int Lp, ndwt::Fused3Args<float>& a, const double* lo, const double* hi) {
+    if (small) {
+#define CASES(LL) case LL: return run_ycs<LL, 16, 8, 512, 2>(a, lo, hi);
+        switch (Lp) {
+            CASES(2) CASES(4) CASES(6) CASES(8) CASES(10) CASES(12) CASES(14) CASES(16)
+            default: return -1;
+        }
+#undef CASES
+    }
+#define CASEP(LL) case LL: return run_ycs<LL, ndwt::inv3y_tx(LL, 2), ndwt::inv3y_ty(LL, 2), 1024, 1>(a, lo, hi);
+    switch (Lp) {
+        CASEP(10) CASEP(12) CASEP(16)
+        default: return -1;
+    }
+#undef CASEP
 }
 #endif
 #if EMU_IN(12)

@@ -241,10 +241,23 @@ def test_emulated_pair_packed_synthesis_complex(emu, sizes, wn, vec4, zchunk, l2
     c = rng.standard_normal(tuple(sizes) + (8,)) + 1j * rng.standard_normal(tuple(sizes) + (8,))
     filt = [orc.wave_filters(w) for w in wn]
     want = orc.spatial_level_rec(c, filt, l2)
-    for variant in ((5, 8) if vec4 else (5,)):
+    for variant in ((5, 8, 10) if vec4 else (5,)):     # 10: the x stage in scatter form (the library's default from 10 taps on)
         got = _run(emu, c, wn, l2, True, np.float32, vec4, zchunk, True, variant=variant, cplx=True)
         assert np.isfinite(got).all(), variant
         assert np.abs(got - want).max() <= 2e-6 * max(np.abs(want).max(), 1.0), variant
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("sizes,wn,zchunk", [((70, 36, 9), ("db5", "db5", "db5"), 0), ((50, 35, 8), ("db6", "db6", "db4"), 4), ((52, 33, 10), ("db8", "db8", "db8"), 0)])
+def test_emulated_pair_packed_synthesis_complex_scatter_form_production_tiles(emu, sizes, wn, zchunk):
+    """Inv3Y<.., EW = 2, XSC> on the library's tiles (64 x 32 for 10 taps, 48 x 32 for 12 .. 16): interleaved complex64 data"""
+    rng = np.random.default_rng(14)
+    c = rng.standard_normal(tuple(sizes) + (8,)) + 1j * rng.standard_normal(tuple(sizes) + (8,))
+    filt = [orc.wave_filters(w) for w in wn]
+    want = orc.spatial_level_rec(c, filt, 1)
+    got = _run(emu, c, wn, 1, True, np.float32, True, zchunk, False, variant=10, cplx=True)
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= 2e-6 * max(np.abs(want).max(), 1.0)
 
 
 @pytest.mark.slow
