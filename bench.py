@@ -15,6 +15,7 @@ Algorithmic bytes: a level-direction moves (1 + 2^d) V s
 algorithmic bytes per launch: fused 3-D level (1 + 8) V 4 B, one-axis pass (1 + 2) V 4 B.
 """
 import argparse
+import importlib
 import json
 import os
 import socket
@@ -275,6 +276,21 @@ def one_rank_share(sh, torch, dev, wname, level, whole_ms, n_local=64, steps=100
     del eng, x
     torch.cuda.empty_cache()
     return out
+
+
+def mplan_host_time(wname, level, whole_ms, slabs=8):
+    """ndwt_mplan_* with 8 slabs of cfg3, all on this device (a child process: tools/mplan_host_time.py): the HOST time ndwt_mdec + ndwt_mrec
+    spend queueing a call for 8 devices -- one worker thread of the plan per slab, and from one thread -- next to one device's share of the
+    compute.  A call whose queueing takes longer than that share would be bound by the host, not by the GPUs (it was: 4.0 ms from one thread
+    at the start of round 4; profiles/r04_mplan_host_time.txt).  None if the child fails."""
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mplan_host_time.py"), str(slabs), wname, str(level), "--json"],
+                           capture_output=True, text=True, timeout=240)
+        res = json.loads(r.stdout.strip().splitlines()[-1])
+        res["whole_volume_ms"] = round(whole_ms, 4)
+        return res
+    except Exception:
+        return None
 
 
 def rccl_self_exchange(wname, level):
@@ -615,6 +631,10 @@ def main():
                 for k, v in rs.items():
                     v["x8_equivalent"] = round(dts * 1e3 / v["ms_per_dec_rec"], 2)
                 share["cfg3"]["with_rccl_batches_to_self"] = rs
+            try:                                                  # the single-process multi-device plan (the path behind one MATLAB process)
+                share["single_process_plan"] = mplan_host_time(a.wname, level, dts * 1e3)
+            except Exception as e:
+                share["single_process_plan"] = {"error": f"{type(e).__name__}: {e}"[:200]}
             out["one_rank_share"] = share
         except Exception as e:
             out["one_rank_share"] = {"error": f"{type(e).__name__}: {e}"[:200]}
