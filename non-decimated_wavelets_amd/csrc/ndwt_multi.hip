@@ -39,6 +39,8 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 #include "../../include/ndwt.h"
 
 namespace {
@@ -89,6 +91,7 @@ struct Team {
     std::function<int(size_t)> job;
     std::vector<int> rc;
     std::vector<std::string> err;
+    pid_t pid = 0;                        // the process that started the workers (a forked child has the plan but not the threads)
 };
 
 struct ndwt_mplan {
@@ -171,8 +174,10 @@ static void team_worker(ndwt_mplan* mp, size_t i) {
 static void team_begin(ndwt_mplan* mp) {
     const size_t G = mp->slabs.size();
     if (!mp->threads || G < 2) return;
+    if (mp->team && mp->team->pid != getpid()) mp->team = nullptr;   // forked: the parent's workers do not exist here (its Team object is left alone)
     if (!mp->team) {
         mp->team = new Team();
+        mp->team->pid = getpid();
         mp->team->rc.assign(G, 0);
         mp->team->err.assign(G, std::string());
         for (size_t i = 1; i < G; ++i) mp->team->th.emplace_back(team_worker, mp, i);
@@ -190,6 +195,7 @@ static void team_end(ndwt_mplan* mp) {
 }
 static void team_destroy(ndwt_mplan* mp) {
     if (!mp->team) return;
+    if (mp->team->pid != getpid()) { mp->team = nullptr; return; }
     {
         std::lock_guard<std::mutex> lk(mp->team->m);
         mp->team->stop = true;
